@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SIFT extraction throughput at 1080p on MI355X.
+
+A step is one pass of the whole hot path (pyramid, detection, orientation,
+descriptors) over one batch of 256 synthetic 1920x1080 float images, 2 scales,
+5 octaves, already resident in HBM.  With N > 1 (launched by torchrun, one rank
+per GPU) every rank owns its own batch: images are independent, there is no
+collective on the data path, so scaling is weak and `value` is the sum over
+ranks divided by the slowest rank's time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, S, O, CAP = 1920, 1080, 2, 5, 2500
+BATCH = 256
+SEED0 = 1000
+HBM_PEAK = 8.0e12  # B/s, MI355X spec
+
+
+def octave_pixels(w, h, n_oct):
+    out = []
+    for _ in range(n_oct):
+        out.append(w * h)
+        w, h = (w + 1) // 2, (h + 1) // 2
+    return out
+
+
+def algorithmic_bytes(s):
+    """Per pixel per octave, float32 planes, two-pass separable design with the
+    DoG fused into the column pass."""
+    return {
+        "row": (1 + (s + 3)) * 4.0,                 # read base, write S+3 row-blurred planes
+        "col": ((s + 3) + s + (s + 2) + 0.25) * 4.0,  # read S+3, write S blur + S+2 DoG + 1/4 next base
+        "detect": (s + 2) * 4.0,                    # read S+2 DoG planes
+        "downsample_read": 0.25 * 4.0,
+    }
+
+
+def gen_images(n, seed0, dense, threads):
+    import sift_amd
+
+    imgs = np.empty((n, H, W), np.float32)
+
+    def one(i):
+        sift_amd.lib().sift_synth_image(imgs[i].ctypes.data, W, W, H, seed0 + i, int(dense))
+
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(one, range(n)))
+    return imgs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--chunk", type=int, default=0, help="images per launch set (0 = library default)")
+    ap.add_argument("--dense", action="store_true", help="high keypoint density images")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=48)
+    args = ap.parse_args()
+
+    import torch
+    import sift_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torchrun", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    sift_amd.lib()  # raises if the HIP library is missing
+    sift_amd.set_params(n_octaves=O, n_scales=S, max_points=CAP)
+    if args.chunk:
+        sift_amd.lib().sift_set_batch_chunk(args.chunk)
+
+    threads = min(16, os.cpu_count() or 1)
+    host = gen_images(args.batch, SEED0 + rank * args.batch, args.dense, threads)
+    d_imgs = torch.from_numpy(host).cuda()
+    d_pts = torch.empty((args.batch * CAP, sift_amd.POINT_FLOATS), dtype=torch.float32, device="cuda")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    counts = None
+    for _ in range(args.warmup):
+        _, counts = sift_amd.extract_batch(d_imgs, W, d_pts=d_pts)
+
+    sift_amd.timing_reset()
+    sift_amd.timing_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, counts = sift_amd.extract_batch(d_imgs, W, d_pts=d_pts)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    sift_amd.timing_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        k = torch.tensor([float(counts.sum())], dtype=torch.float64, device="cuda")
+        dist.all_reduce(k, op=dist.ReduceOp.SUM)
+        keypoints_per_step = float(k.item())
+    else:
+        keypoints_per_step = float(counts.sum())
+
+    images = args.batch * args.steps * world
+    value = images / elapsed
+
+    out = {
+        "metric": "images/sec at 1080p (keypoints + 128-D descriptors, whole job)",
+        "value": value,
+        "unit": "images/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.batch} synthetic {W}x{H} f32 images per GPU, {S} scales, {O} octaves, "
+                        f"cap {CAP}, semantics profile ref, inputs resident in HBM"
+                        + (", dense blobs" if args.dense else ""),
+            "parallelism": f"dp{world} (independent image batches, no collective)",
+        },
+        "keypoints_per_s": keypoints_per_step * args.steps / elapsed,
+        "keypoints_per_image": keypoints_per_step / (args.batch * world),
+    }
+
+    if rank == 0:
+        ab = algorithmic_bytes(S)
+        px = sum(octave_pixels(W, H, O))
+        names = {"row": sift_amd.K_ROW_BLUR, "col": sift_amd.K_COL_BLUR_DOG,
+                 "detect": sift_amd.K_DETECT, "keypoint": sift_amd.K_KEYPOINT}
+        kern = {}
+        for name, kid in names.items():
+            ms, n = sift_amd.timing_read(kid)
+            kern[name] = {"ms_total": ms, "launches": n}
+        # dominant pyramid kernel = the one with the most device time
+        dom = max(("row", "col", "detect"), key=lambda k: kern[k]["ms_total"])
+        dom_ms, dom_n = kern[dom]["ms_total"], max(kern[dom]["launches"], 1)
+        bytes_total = ab[dom] * px * args.batch * args.steps  # this rank
+        achieved = bytes_total / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
+        out["roofline"] = {
+            "bound": "hbm",
+            "kernel": {"row": "row_blur_kernel", "col": "col_blur_dog_kernel", "detect": "detect_kernel"}[dom],
+            "achieved": achieved / 1e9,
+            "peak": HBM_PEAK / 1e9,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK,
+            "traffic": None,
+            "bytes_per_launch": bytes_total / dom_n,
+            "avg_launch_ms": dom_ms / dom_n,
+            "launches": dom_n,
+        }
+        pyr_ms = sum(kern[k]["ms_total"] for k in ("row", "col", "detect"))
+        pyr_bytes = (ab["row"] + ab["col"] + ab["detect"]) * px * args.batch * args.steps
+        out["pyramid"] = {
+            "algorithmic_GB_per_image": (ab["row"] + ab["col"] + ab["detect"]) * px / 1e9,
+            "kernel_ms": {k: v["ms_total"] for k, v in kern.items()},
+            "achieved_GBps": pyr_bytes / (pyr_ms * 1e-3) / 1e9 if pyr_ms > 0 else 0.0,
+            "frac": pyr_bytes / (pyr_ms * 1e-3) / HBM_PEAK if pyr_ms > 0 else 0.0,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            import oracle
+
+            pr = oracle.params(n_octaves=O, n_scales=S, max_points=CAP)
+            n_cpu = min(args.cpu_sample, args.batch)
+            t0 = time.perf_counter()
+            _, cpu_counts = oracle.extract_batch(pr, host[:n_cpu], W, n_threads=threads)
+            dt = time.perf_counter() - t0
+            out["cpu_baseline"] = {
+                "value": n_cpu / dt,
+                "unit": "images/s",
+                "cores": threads,
+                "kind": "port",
+                "sample": f"first {n_cpu} images of the same batch, C restatement of the reference "
+                          f"kernels, one image per thread",
+                "keypoints_match_gpu": bool(np.array_equal(cpu_counts, counts[:n_cpu])),
+            }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,162 @@
+/*
+ * sift_amd -- MI355X (gfx950) SIFT extractor, C ABI.
+ *
+ * Drop-in boundary for the reference pipeline IjlalBaig/SIFT (Sift/src): the
+ * four functions sift.cu calls (Sift/src/sift.cu:99-125) keep their names and
+ * argument order; the CUDA stream reference becomes an opaque handle by value.
+ * Everything is plain C: pointers, ints, floats.  No HIP type appears here.
+ *
+ * All device pointers are owned by the caller.  The library owns one scratch
+ * arena per stream slot, sized on first use and reused afterwards.
+ */
+#ifndef SIFT_AMD_H
+#define SIFT_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Sift/src/sift.h:7-13 -- 528-byte POD, identical layout. */
+typedef struct {
+    float xpos;        /* integer pixel column in the octave's own grid */
+    float ypos;        /* integer pixel row in the octave's own grid */
+    float scale;       /* 1.6 * sqrt(2)^(scaleIdx + nScales*octave), cudaSiftH.cu:94-95 */
+    float orientation; /* degrees, multiple of 11.25 */
+    float data[128];   /* L1-normalised 4x4x8 histogram */
+} SiftPoint;
+
+/* Runtime mirror of the compile-time configuration in Sift/src/utils.h:4-19.
+ * A non-default value behaves as the reference would if recompiled with it
+ * (the scale ratio stays sqrt(2) and the blur stays 19 taps). */
+typedef struct {
+    int n_octaves;        /* N_OCTAVES      4     utils.h:7  (1..8)  */
+    int n_scales;         /* N_SCALES       2     utils.h:8  (2 or 3) */
+    int max_points;       /* MAX_POINTCOUNT 2500  utils.h:10 */
+    float sigma;          /* SIGMA          1.6f  utils.h:14 */
+    float r_thresh;       /* R_THRESH       10.0f utils.h:16 */
+    float extrema_thresh; /* EXTREMA_THRESH 10.0f utils.h:18 */
+} sift_params;
+
+#define SIFT_MAX_OCTAVES 8
+#define SIFT_MAX_SLOTS 8 /* the reference has 2: d_PointCount[2], cudaSiftD.h:24-25 */
+
+/* ---- the reference's entry points (Sift/src/cudaSiftH.h:6-30) ------------- */
+
+/* cudaSiftH.cu:128-157 -- builds the Gaussian tap tables (host side; they
+ * travel to the kernels as launch arguments, so there is nothing to upload). */
+void initDeviceConstant(void);
+/* cudaSiftH.cu:120-127 -- zeroes the point counter of every stream slot on
+ * the current device (synchronous, like the reference's symbol copy). */
+void initDeviceVariables(void);
+/* cudaSiftH.cu:9-60 -- one image: octaves octaveIdx..n_octaves-1, appending
+ * keypoints with orientation and descriptor to siftPt (device array of
+ * max_points entries) behind the slot's current count.  d_src: device image,
+ * pitch in floats (cudaImage.cu:31-32).  stream: hipStream_t passed as void*
+ * (NULL = default stream).  streamIdx selects the slot (0..SIFT_MAX_SLOTS-1).
+ * Asynchronous: returns after enqueueing; errors via sift_last_error(). */
+void extractSift(SiftPoint *siftPt, float *d_src, int width, int pitch, int height,
+                 void *stream, int streamIdx, int octaveIdx);
+/* cudaSiftH.cu:323-328 -- waits for the slot's work, returns its point count
+ * (clamped to max_points), or -1 on error. */
+int getPointCount(int streamIdx);
+
+/* ---- stage launchers (Sift/src/cudaSiftH.h:17-20), dense planes -----------
+ * Plane i of a multi-plane buffer starts at base + i*pitch*height floats, as
+ * in the reference.  All asynchronous on `stream`. */
+/* cudaSiftH.cu:210-259: src -> dst[(S+3) planes], both passes */
+void blurOctave(float *dst, float *src, int width, int pitch, int height, void *stream);
+/* cudaSiftH.cu:306-316: src[(S+3)] -> dst[(S+2)] */
+void computeDiffOfGauss(float *dst, float *src, int width, int pitch, int height, void *stream);
+/* cudaSiftH.cu:260-283: src[(S+3)] blur planes -> dst[3S] (Dxx,Dyy,Dxy per scale) */
+void computeHessian(float *dst, float *src, int width, int pitch, int height, void *stream);
+/* cudaSiftH.cu:284-305: src[(S+3)] blur planes -> dst[2S] (magnitude, direction per scale) */
+void computeGradient(float *dst, float *src, int width, int pitch, int height, void *stream);
+/* cudaSiftH.cu:317-322 */
+void copyDeviceData(float *dst, float *src, int width, int pitch, int height, void *stream);
+
+/* ---- configuration and errors (not in the reference: it uses macros and
+ * exit(1), utils.h:4-19, cudaUtils.h:8-15) ---------------------------------- */
+void sift_default_params(sift_params *p);
+int sift_set_params(const sift_params *p); /* 0 = ok; rebuilds the tables */
+void sift_get_params(sift_params *p);
+/* message of the most recent failure on this thread's library state, "" if none */
+const char *sift_last_error(void);
+void sift_clear_error(void);
+/* tap tables as the kernels receive them: blur[(S+3)*19], wnd[S*16], desc[16] */
+void sift_get_tables(float *blur, float *wnd, float *desc);
+/* frees every arena on the current device */
+void sift_shutdown(void);
+
+/* ---- batch entry (not in the reference: it loops over image pairs,
+ * sift.cu:68-134).  n images of identical geometry, image i at
+ * d_imgs + i*img_stride floats; points of image i at d_pts + i*max_points;
+ * h_counts[i] (host) receives the clamped count.  d_meta (optional, device,
+ * 2 bytes per point slot) receives {octave, scale index}.  Blocks until done.
+ * Returns 0 or a negative error. */
+int sift_extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
+                       const float *d_imgs, long img_stride, int n,
+                       int width, int pitch, int height, void *stream);
+/* images worked on per launch set (default 8); arenas grow to match */
+void sift_set_batch_chunk(int images_per_launch);
+
+/* ---- thin device layer (replaces CudaImage / SiftData helpers,
+ * cudaImage.cu:23-68, sift.cu:30-61, and the stream calls in sift.cu:94-130) */
+int sift_device_count(void);
+int sift_set_device(int dev);
+int sift_dev_malloc(void **p, size_t bytes);
+int sift_dev_malloc_pitch(float **p, int *pitch_floats, int width, int height);
+int sift_dev_free(void *p);
+int sift_memcpy2d_h2d_async(float *d_dst, int d_pitch, const float *h_src, int h_pitch,
+                            int width, int height, void *stream);
+int sift_memcpy2d_d2h_async(float *h_dst, int h_pitch, const float *d_src, int d_pitch,
+                            int width, int height, void *stream);
+int sift_memcpy_h2d_async(void *d_dst, const void *h_src, size_t bytes, void *stream);
+int sift_memcpy_d2h_async(void *h_dst, const void *d_src, size_t bytes, void *stream);
+int sift_stream_create(void **stream);
+int sift_stream_destroy(void *stream);
+int sift_stream_sync(void *stream);
+int sift_host_alloc_pinned(void **p, size_t bytes);
+int sift_host_free_pinned(void *p);
+
+/* ---- host pipeline (counterpart of Sift/src/sift.cu:64-163, utils.cc:8-17) ---
+ * Binary PGM/PPM -> float grey image (malloc'ed; release with sift_free_host).
+ * Colour is reduced as the reference's OpenCV grayscale load does:
+ * Y = (1868*B + 9617*G + 4899*R + 8192) >> 14. */
+int sift_load_pnm_gray(const char *path, float **out, int *width, int *height);
+void sift_free_host(void *p);
+/* sift.cu:151-160 text format; returns bytes written into buf or -1 */
+long sift_format_points(const SiftPoint *pts, int n, char *buf, long cap);
+/* sift.cu:144-163: writes <dst_dir>/<basename(src_path)>.sift.txt */
+int sift_save_points(const char *dst_dir, const char *src_path, const SiftPoint *pts, int n);
+/* sift.cu:64-143: images two at a time on two streams and two counter slots */
+int sift(const char *dst_dir, const char **src_paths, int n_imgs);
+/* the reference hands count-1 to its writer (sift.cu:125); 1 reproduces that */
+void sift_pipeline_drop_last_point(int on);
+
+/* ---- measurement hooks ---------------------------------------------------- */
+enum {
+    SIFT_K_ROW_BLUR = 0,
+    SIFT_K_COL_BLUR_DOG = 1,
+    SIFT_K_DETECT = 2,
+    SIFT_K_KEYPOINT = 3,
+    SIFT_K_COUNT = 4
+};
+/* When enabled, every launch of the pyramid kernels is bracketed by events on
+ * its own stream; sift_timing_read drains them (synchronises). */
+void sift_timing_enable(int on);
+/* total milliseconds and number of launches per kernel since the last reset */
+int sift_timing_read(int kernel, double *ms_total, long *launches);
+void sift_timing_reset(void);
+
+/* ---- synthetic input (deterministic, no dependencies) ---------------------
+ * 128 + value noise + Gaussian blobs + pixel noise, clamped to [0,255] and
+ * rounded to integers; dense != 0 selects the high-keypoint-density variant. */
+void sift_synth_image(float *dst, int width, int pitch, int height, unsigned long long seed,
+                      int dense);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,759 @@
+/*
+ * CPU restatement of the reference SIFT path -- TEST INFRASTRUCTURE ONLY
+ * (see sift_oracle.h for the pinning statement and the semantics profile).
+ *
+ * Build: gcc -O2 -ftree-vectorize -ffp-contract=off -mfma -mavx2 (Makefile).
+ * Every fused multiply-add the reference performs is written as fmaf();
+ * nothing else may be contracted.
+ */
+#include "sift_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define REF_PI 3.14159265 /* utils.h:4 */
+#define TAPS ORACLE_BLUR_TAPS
+#define RADIUS 9 /* B_KERNEL_RADIUS utils.h:5 */
+
+void oracle_default_params(OracleParams *p)
+{
+    p->n_octaves = 4;
+    p->n_scales = 2;
+    p->max_points = 2500;
+    p->sigma = 1.6f;
+    p->r_thresh = 10.0f;
+    p->extrema_thresh = 10.0f;
+}
+
+int oracle_idivup(int num, int den) { return (num % den != 0) ? (num / den + 1) : (num / den); }
+int oracle_ialignup(int A, int a) { return (A % a != 0) ? (A + a - A % a) : A; }
+
+/* utils.cc:41-53.  C++ promotion rules of the original expression: 2.0f*PI is
+ * double, pow(float,int) and pow(double,float) evaluate in double, the product
+ * is rounded to float on store, the running sum and the division are float. */
+void oracle_gaussian1d(float *kp, float sigma, int n)
+{
+    float sum = 0;
+    for (int i = 0; i < n; ++i) {
+        float d = (float)i - ((float)(n - 1) / 2);
+        double norm = 1 / (pow(2.0f * REF_PI, (double)0.5f) * (double)sigma);
+        double e = exp(-pow((double)d, 2) / (2 * pow((double)sigma, 2)));
+        kp[i] = (float)(norm * e);
+        sum += kp[i];
+    }
+    for (int i = 0; i < n; ++i)
+        kp[i] /= sum;
+}
+
+/* cudaSiftH.cu:128-157 */
+void oracle_tables(const OracleParams *p, float *blur, float *wnd, float *desc)
+{
+    float k = (float)pow(2, 0.5);
+    int S = p->n_scales;
+    for (int i = 0; i < S + 3; ++i) {
+        float sigmaNew = (float)(pow((double)k, (double)(i - 1)) * (double)p->sigma);
+        oracle_gaussian1d(blur + i * TAPS, sigmaNew, TAPS);
+    }
+    for (int i = 0; i < S; ++i) {
+        float sigmaNew = (float)(pow((double)k, (double)i) * (double)p->sigma * 1.5);
+        oracle_gaussian1d(wnd + i * ORACLE_WND_TAPS, sigmaNew, ORACLE_WND_TAPS);
+    }
+    float sigmaNew = (float)((double)p->sigma * 1.5);
+    oracle_gaussian1d(desc, sigmaNew, 16);
+}
+
+/* cudaSiftH.cu:94-95 */
+float oracle_scale_value(const OracleParams *p, int i, int octaveIdx)
+{
+    float k = (float)pow(2, 0.5);
+    return (float)(pow((double)k, (double)(i + p->n_scales * octaveIdx)) * (double)p->sigma);
+}
+
+void oracle_rotation_table(float *c32, float *s32)
+{
+    for (int k = 0; k < 32; ++k) {
+        double rad = (double)(11.25f * (float)k) * (3.14159265358979323846 / 180.0);
+        c32[k] = (float)cos(rad);
+        s32[k] = (float)sin(rad);
+    }
+}
+
+/* ---- deterministic atan2f ------------------------------------------------
+ * The reference calls the CUDA device atan2f (cudaSiftD.cu:356), which is not
+ * available.  This evaluation uses only IEEE double +,-,*,/ and fma in a fixed
+ * order, so the same source gives the same bits on any IEEE machine; the
+ * double result (rel. error < 1e-13) is rounded once to float. */
+static double atan_small(double t) /* |t| <= tan(pi/8) */
+{
+    static const double C[17] = {
+        -1.0 / 3.0,  1.0 / 5.0,  -1.0 / 7.0,  1.0 / 9.0,  -1.0 / 11.0, 1.0 / 13.0,
+        -1.0 / 15.0, 1.0 / 17.0, -1.0 / 19.0, 1.0 / 21.0, -1.0 / 23.0, 1.0 / 25.0,
+        -1.0 / 27.0, 1.0 / 29.0, -1.0 / 31.0, 1.0 / 33.0, -1.0 / 35.0};
+    double s = t * t;
+    double q = C[16];
+    for (int k = 15; k >= 0; --k)
+        q = fma(q, s, C[k]);
+    return fma(t * s, q, t);
+}
+
+float oracle_atan2f(float yf, float xf)
+{
+    double x = (double)xf, y = (double)yf;
+    double ax = fabs(x), ay = fabs(y);
+    double mx = ax > ay ? ax : ay;
+    double mn = ax > ay ? ay : ax;
+    double r;
+    if (mx == 0.0) {
+        r = 0.0;
+    } else {
+        double a = mn / mx;
+        if (a > 0.41421356237309503) {
+            double t = (a - 1.0) / (a + 1.0);
+            r = 0.78539816339744831 + atan_small(t);
+        } else {
+            r = atan_small(a);
+        }
+    }
+    if (ay > ax)
+        r = 1.57079632679489662 - r;
+    if (x < 0.0)
+        r = 3.14159265358979323846 - r;
+    if (y < 0.0)
+        r = -r;
+    return (float)r;
+}
+
+/* cudaSiftD.h:35-41 */
+int oracle_assign_bin(float theta, int nBins)
+{
+    float binRange = 360.0f / (float)nBins;
+    theta = (theta < 0) ? (theta + 360) : theta;
+    theta = fmodf(theta, 360.0f);
+    return (int)floorf(theta / binRange);
+}
+
+/* ---- pyramid --------------------------------------------------------------*/
+
+/* xblurMultiKernel cudaSiftD.cu:430-486 with the zero-filling tile loader
+ * cudaSiftD.h:43-78: out_i[x,y] = chain_k fmaf(c[i*19+k], src[x-9+k,y], sum),
+ * sum0 = 0, k ascending; src is 0 outside [0,w). */
+void oracle_xblur(const OracleParams *pr, const float *src, float *tmp, int w, int p, int h)
+{
+    float taps[8 * TAPS], wnd[8 * 16], desc[16];
+    oracle_tables(pr, taps, wnd, desc);
+    int nP = pr->n_scales + 3;
+    long gDim = (long)p * h;
+    float *row = (float *)malloc(sizeof(float) * (w + 2 * RADIUS));
+    float *acc = (float *)malloc(sizeof(float) * w);
+    for (int y = 0; y < h; ++y) {
+        for (int x = 0; x < RADIUS; ++x) {
+            row[x] = 0.0f;
+            row[w + RADIUS + x] = 0.0f;
+        }
+        memcpy(row + RADIUS, src + (long)y * p, sizeof(float) * w);
+        for (int i = 0; i < nP; ++i) {
+            const float *c = taps + i * TAPS;
+            for (int x = 0; x < w; ++x)
+                acc[x] = 0.0f;
+            for (int k = 0; k < TAPS; ++k) {
+                float ck = c[k];
+                const float *s = row + k;
+                for (int x = 0; x < w; ++x)
+                    acc[x] = fmaf(ck, s[x], acc[x]);
+            }
+            memcpy(tmp + i * gDim + (long)y * p, acc, sizeof(float) * w);
+        }
+    }
+    free(row);
+    free(acc);
+}
+
+/* yblurKernel cudaSiftD.cu:488-534: column chain, zero outside [0,h). */
+void oracle_yblur(const OracleParams *pr, const float *tmp, float *blur, int w, int p, int h)
+{
+    float taps[8 * TAPS], wnd[8 * 16], desc[16];
+    oracle_tables(pr, taps, wnd, desc);
+    int nP = pr->n_scales + 3;
+    long gDim = (long)p * h;
+    float *acc = (float *)malloc(sizeof(float) * w);
+    for (int i = 0; i < nP; ++i) {
+        const float *c = taps + i * TAPS;
+        const float *src = tmp + i * gDim;
+        for (int y = 0; y < h; ++y) {
+            for (int x = 0; x < w; ++x)
+                acc[x] = 0.0f;
+            for (int j = 0; j < TAPS; ++j) {
+                int yy = y - RADIUS + j;
+                float cj = c[j];
+                if (yy >= 0 && yy < h) {
+                    const float *s = src + (long)yy * p;
+                    for (int x = 0; x < w; ++x)
+                        acc[x] = fmaf(cj, s[x], acc[x]);
+                } else {
+                    for (int x = 0; x < w; ++x)
+                        acc[x] = fmaf(cj, 0.0f, acc[x]);
+                }
+            }
+            memcpy(blur + i * gDim + (long)y * p, acc, sizeof(float) * w);
+        }
+    }
+    free(acc);
+}
+
+/* subtractKernel cudaSiftD.cu:5-15, launched for i = 0..S+1 (cudaSiftH.cu:314-315) */
+void oracle_dog(const OracleParams *pr, const float *blur, float *dog, int w, int p, int h)
+{
+    long gDim = (long)p * h;
+    for (int i = 0; i < pr->n_scales + 2; ++i)
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                long g = x + (long)p * y;
+                dog[i * gDim + g] = blur[i * gDim + g] - blur[(i + 1) * gDim + g];
+            }
+}
+
+static inline float zpad(const float *pl, int w, int p, int h, int x, int y)
+{
+    return (x >= 0 && x < w && y >= 0 && y < h) ? pl[x + (long)p * y] : 0.0f;
+}
+
+/* hessianKernel cudaSiftD.cu:366-428; source plane i+1 (cudaSiftH.cu:278) */
+void oracle_hessian(const OracleParams *pr, const float *blur, float *hess, int w, int p, int h)
+{
+    long gDim = (long)p * h;
+    for (int i = 0; i < pr->n_scales; ++i) {
+        const float *src = blur + (i + 1) * gDim;
+        float *dst = hess + (long)i * 3 * gDim;
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                float c = src[x + (long)p * y];
+                float Dxx = -2 * c;
+                Dxx += zpad(src, w, p, h, x - 1, y);
+                Dxx += zpad(src, w, p, h, x + 1, y);
+                float Dyy = -2 * c;
+                Dyy += zpad(src, w, p, h, x, y - 1);
+                Dyy += zpad(src, w, p, h, x, y + 1);
+                float Dxy = c;
+                Dxy += zpad(src, w, p, h, x - 1, y - 1);
+                Dxy -= zpad(src, w, p, h, x - 1, y);
+                Dxy -= zpad(src, w, p, h, x, y - 1);
+                long g = x + (long)p * y;
+                dst[g] = Dxx;
+                dst[g + gDim] = Dyy;
+                dst[g + 2 * gDim] = Dxy;
+            }
+    }
+}
+
+/* one gradient sample as gradientKernel computes it (cudaSiftD.cu:349-356) */
+static inline void grad_at(const float *src, int w, int p, int h, int x, int y, float *mag,
+                           float *dir)
+{
+    float lUp = zpad(src, w, p, h, x, y - 1);
+    float lDown = zpad(src, w, p, h, x, y + 1);
+    float lLeft = zpad(src, w, p, h, x - 1, y);
+    float lRight = zpad(src, w, p, h, x + 1, y);
+    float dx = lRight - lLeft;
+    float dy = lDown - lUp;
+    float dx2 = dx * dx; /* powf(v, 2) is v*v correctly rounded */
+    float dy2 = dy * dy;
+    *mag = sqrtf(dx2 + dy2);
+    *dir = (float)((180 / REF_PI) * (double)oracle_atan2f(dy, dx));
+}
+
+/* gradientKernel cudaSiftD.cu:306-364; source plane i+1 (cudaSiftH.cu:300) */
+void oracle_gradient(const OracleParams *pr, const float *blur, float *grad, int w, int p, int h)
+{
+    long gDim = (long)p * h;
+    for (int i = 0; i < pr->n_scales; ++i) {
+        const float *src = blur + (i + 1) * gDim;
+        float *dst = grad + (long)i * 2 * gDim;
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                long g = x + (long)p * y;
+                grad_at(src, w, p, h, x, y, &dst[g], &dst[g + gDim]);
+            }
+    }
+}
+
+/* resizeKernel cudaSiftD.cu:544-559: even pixels, dst pitch alignUp(ceil(w/2),128) */
+void oracle_downsample(const float *src, float *dst, int w, int p, int h)
+{
+    int p_ = oracle_ialignup(oracle_idivup(w, 2), 128);
+    for (int y = 0; y < h; y += 2)
+        for (int x = 0; x < w; x += 2)
+            dst[x / 2 + (long)(y / 2) * p_] = src[x + (long)p * y];
+}
+
+/* ---- detection ------------------------------------------------------------
+ * Launch geometry of findExtremaKernel (cudaSiftH.cu:64-89): 32x32 threads,
+ * nTilesX = 3, apron 1 on every side, bankOffset 3. */
+#define XT_BDIM 32
+#define XT_NTILES 3
+#define XT_DATAX (XT_NTILES * XT_BDIM)          /* 96 */
+#define XT_SDIMX (1 + XT_DATAX + 1 + 3)         /* 101 */
+#define XT_SDIMY (1 + XT_BDIM + 1)              /* 34 */
+#define XT_WRITTEN (XT_SDIMX - 3)               /* loader writes sx < 98 */
+#define XT_PLANE_OFF ((XT_DATAX + 3) * XT_BDIM) /* 3168, cudaSiftD.cu:240-241 */
+#define XT_SMEM ((3 * 3 * 32 + 2 + 3) * 34)     /* 9962 floats, cudaSiftH.cu:73-74 */
+
+/* Value a thread of block (bx,by) reads from tile `s` at (sx,sy) after the
+ * three sequential tile loads (cudaSiftD.cu:250-261).  The tiles are 101x34
+ * but spaced only 3168 floats apart, so the head of tile s+1 overwrites the
+ * tail of tile s, except in the columns the loader never writes. */
+static float tile_read(const float *dog3, int w, int p, int h, int bx, int by, int s, int sx,
+                       int sy)
+{
+    long gDim = (long)p * h;
+    if (s < 2) {
+        int lin = sx + XT_SDIMX * sy;
+        if (lin >= XT_PLANE_OFF) {
+            int j = lin - XT_PLANE_OFF;
+            int sx2 = j % XT_SDIMX, sy2 = j / XT_SDIMX;
+            if (sx2 < XT_WRITTEN) {
+                s = s + 1;
+                sx = sx2;
+                sy = sy2;
+            }
+        }
+    }
+    return zpad(dog3 + s * gDim, w, p, h, XT_DATAX * bx - 1 + sx, XT_BDIM * by - 1 + sy);
+}
+
+/* contribution of one (thread, tile) visit to pxRank (cudaSiftD.cu:271-284) */
+int oracle_pixel_rank(const float *dog3, int w, int p, int h, int x, int y, float *center)
+{
+    int bx = x / XT_DATAX, by = y / XT_BDIM;
+    int sx = 1 + x % XT_DATAX, sy = 1 + y % XT_BDIM;
+    float pxVal = tile_read(dog3, w, p, h, bx, by, 1, sx, sy);
+    int r = 0;
+    for (int l = -1; l < 2; ++l)
+        for (int m = -1; m < 2; ++m)
+            for (int s = 0; s < 3; ++s)
+                r += (pxVal >= tile_read(dog3, w, p, h, bx, by, s, sx + l, sy + m)) ? 1 : -1;
+    if (center)
+        *center = pxVal;
+    return r;
+}
+
+/* acceptance test of cudaSiftD.cu:286-294 without the counter clause */
+static int accept_point(const OracleParams *pr, const float *hess3, int w, int p, int h, int x,
+                        int y, int pxRank, float pxVal)
+{
+    long gDim = (long)p * h;
+    if (!(x > 8 && x < w - 8 && y > 8 && y < h - 8))
+        return 0;
+    if (pxRank != 9)
+        return 0;
+    long g = x + (long)p * y;
+    float Dxx = hess3[g], Dyy = hess3[g + gDim], Dxy = hess3[g + 2 * gDim];
+    float trace = Dxx + Dyy;
+    float prod = Dxx * Dyy;
+    float sq = Dxy * Dxy;
+    float det = prod + sq; /* PLUS, cudaSiftD.cu:288 */
+    float lhs = trace * trace;
+    lhs = lhs / det;
+    float rhs = (pr->r_thresh * pr->r_thresh) / pr->r_thresh;
+    if (!(lhs < rhs))
+        return 0;
+    if (!(fabsf(pxVal) > pr->extrema_thresh))
+        return 0;
+    return 1;
+}
+
+int oracle_find_extrema_closed(const OracleParams *pr, const float *dog3, const float *hess3,
+                               int w, int p, int h, int *xy, int max_out)
+{
+    int n = 0;
+    for (int y = 9; y < h - 8; ++y)
+        for (int x = 9; x < w - 8; ++x) {
+            int tile = (x % XT_DATAX) / XT_BDIM;
+            if (tile == 1)
+                continue; /* r0 + r1 is even, never 9 */
+            float pv;
+            int r = oracle_pixel_rank(dog3, w, p, h, x, y, &pv);
+            if (tile == 2) { /* pxRank is never reset between tiles, cudaSiftD.cu:243,263 */
+                r += oracle_pixel_rank(dog3, w, p, h, x - 64, y, NULL);
+                r += oracle_pixel_rank(dog3, w, p, h, x - 32, y, NULL);
+            }
+            if (accept_point(pr, hess3, w, p, h, x, y, r, pv)) {
+                if (n < max_out) {
+                    xy[2 * n] = x;
+                    xy[2 * n + 1] = y;
+                }
+                ++n;
+            }
+        }
+    return n;
+}
+
+/* Literal simulation: one shared array per block, the three cooperative tile
+ * loads of cudaSiftD.h:43-78 run to completion one after another (each ends in
+ * a barrier), then every thread runs the loop of cudaSiftD.cu:263-304. */
+static void literal_load(float *s, const float *g, int tx, int ty, int gx, int gy, int w, int p,
+                         int h)
+{
+    const int bDimX = 32, bDimY = 32, nTilesX = 3, nTilesY = 1;
+    const int apronLeft = 1, apronRight = 1, apronUp = 1, apronDown = 1, bankOffset = 3;
+    int sDimX = apronLeft + bDimX * nTilesX + apronRight + bankOffset;
+    int sDimY = apronUp + bDimY * nTilesY + apronDown;
+    int apronBlocksX = oracle_idivup(apronLeft, bDimX) + oracle_idivup(apronRight, bDimX);
+    int apronBlocksY = oracle_idivup(apronUp, bDimY) + oracle_idivup(apronDown, bDimY);
+    int jLoop = nTilesY + apronBlocksY;
+    int iLoop = nTilesX + apronBlocksX;
+    for (int j = 0; j < jLoop; ++j) {
+        int sy = ty + j * bDimY;
+        for (int i = 0; i < iLoop; ++i) {
+            int sx = tx + i * bDimX;
+            if (sx >= 0 && sx < sDimX - bankOffset && sy >= 0 && sy < sDimY) {
+                int gx_ = gx - apronLeft + i * bDimX;
+                int gy_ = gy - apronUp + j * bDimY;
+                if (gx_ >= 0 && gx_ < w && gy_ >= 0 && gy_ < h)
+                    s[sx + sy * sDimX] = g[gx_ + (long)gy_ * p];
+                else
+                    s[sx + sy * sDimX] = 0;
+            }
+        }
+    }
+}
+
+int oracle_find_extrema_literal(const OracleParams *pr, const float *dog3, const float *hess3,
+                                int w, int p, int h, int *xy, int max_out)
+{
+    long gDim = (long)p * h;
+    int n = 0;
+    float *shared = (float *)malloc(sizeof(float) * XT_SMEM);
+    int gridX = oracle_idivup(w, XT_DATAX), gridY = oracle_idivup(h, XT_BDIM);
+    const int sDimX = XT_SDIMX;
+    for (int bIdxY = 0; bIdxY < gridY; ++bIdxY)
+        for (int bIdxX = 0; bIdxX < gridX; ++bIdxX) {
+            for (int i = 0; i < XT_SMEM; ++i)
+                shared[i] = NAN; /* uninitialised shared memory */
+            float *sharedScale0 = shared;
+            float *sharedScale1 = shared + (XT_DATAX + 3) * 32;
+            float *sharedScale2 = shared + 2 * (XT_DATAX + 3) * 32;
+            float *tiles[3] = {sharedScale0, sharedScale1, sharedScale2};
+            for (int s = 0; s < 3; ++s)
+                for (int ty = 0; ty < 32; ++ty)
+                    for (int tx = 0; tx < 32; ++tx)
+                        literal_load(tiles[s], dog3 + s * gDim, tx, ty, tx + 32 * bIdxX * 3,
+                                     ty + 32 * bIdxY, w, p, h);
+            for (int ty = 0; ty < 32; ++ty)
+                for (int tx = 0; tx < 32; ++tx) {
+                    int gx = tx + 32 * bIdxX * 3;
+                    int gy = ty + 32 * bIdxY;
+                    float pxRank = 0.0f;
+                    for (int i = 0; i < 3; ++i) {
+                        int gx_ = gx + i * 32;
+                        if (gx_ < w || gy < h) {
+                            int sx = 1 + tx + i * 32;
+                            int sy = 1 + ty;
+                            float pxVal = sharedScale1[sx + sy * sDimX];
+                            for (int l = -1; l < 2; ++l)
+                                for (int m = -1; m < 2; ++m) {
+                                    pxRank += (pxVal >= sharedScale0[sx + l + (sy + m) * sDimX]) ? 1.0f : -1.0f;
+                                    pxRank += (pxVal >= sharedScale1[sx + l + (sy + m) * sDimX]) ? 1.0f : -1.0f;
+                                    pxRank += (pxVal >= sharedScale2[sx + l + (sy + m) * sDimX]) ? 1.0f : -1.0f;
+                                }
+                            if (gx_ > 8 && gx_ < w - 8 && gy > 8 && gy < h - 8 &&
+                                accept_point(pr, hess3, w, p, h, gx_, gy, (int)pxRank, pxVal) &&
+                                pxRank == 9.0f) {
+                                if (n < max_out) {
+                                    xy[2 * n] = gx_;
+                                    xy[2 * n + 1] = gy;
+                                }
+                                ++n;
+                            }
+                        }
+                    }
+                }
+        }
+    free(shared);
+    return n;
+}
+
+/* ---- orientation (intent of OrientationKernel, cudaSiftD.cu:17-94) --------
+ * 16x16 patch [x-7,x+8] x [y-7,y+8]; weight mag*g[tx]*g[ty]; 32 bins; argmax,
+ * first maximum wins; orientation = 11.25*bin degrees.
+ * Summation order (the reference leaves it to shared-memory atomics): each
+ * bin is the sum over samples 0..127 (index ty*16+tx, ascending) plus the sum
+ * over samples 128..255 (ascending). */
+float oracle_orientation(const float *grad2, int w, int p, int h, const float *g16, int x, int y,
+                         float *hist32)
+{
+    long gDim = (long)p * h;
+    float half[2][32];
+    memset(half, 0, sizeof(half));
+    for (int ty = 0; ty < 16; ++ty)
+        for (int tx = 0; tx < 16; ++tx) {
+            long g = (x - 7 + tx) + (long)p * (y - 7 + ty);
+            float m = grad2[g];
+            float d = grad2[g + gDim];
+            float wgt = m * g16[tx];
+            wgt = wgt * g16[ty];
+            int b = oracle_assign_bin(d, 32);
+            int s = ty * 16 + tx;
+            half[s >> 7][b] += wgt;
+        }
+    float hist[32];
+    for (int b = 0; b < 32; ++b)
+        hist[b] = half[0][b] + half[1][b];
+    float best = hist[0];
+    for (int b = 1; b < 32; ++b)
+        best = fmaxf(best, hist[b]);
+    int idx = 0;
+    for (int b = 0; b < 32; ++b)
+        if (hist[b] == best) {
+            idx = b;
+            break;
+        }
+    if (hist32)
+        memcpy(hist32, hist, sizeof(hist));
+    (void)w;
+    return 360.0f / 32.0f * (float)idx;
+}
+
+/* ---- descriptor (intent of DescriptorKernel, cudaSiftD.cu:96-214) ---------
+ * sample (tx,ty): offset (dx,dy) = (tx-7.5, ty-7.5) rotated by
+ * u = dx*cos + dy*sin, v = dy*cos - dx*sin (cudaSiftD.cu:141-142), bilinear
+ * fetch of magnitude and direction with clamp-to-edge, window c_DescWnd, hard
+ * binning floor(dir/45), cell (tx/4, ty/4), index bin + 8*cx + 32*cy, then
+ * L1 normalise, clamp 0.2, L1 normalise (cudaSiftD.cu:186-200). */
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline float lerpf(float a, float b, float t) { return fmaf(t, b - a, a); }
+
+static float warp32_sum(const float *h) /* shflsum cudaSiftD.h:96-106, lane 0 */
+{
+    float a[32];
+    memcpy(a, h, sizeof(a));
+    for (int off = 16; off >= 1; off >>= 1)
+        for (int j = 0; j < off; ++j)
+            a[j] = a[j] + a[j + off];
+    return a[0];
+}
+
+static float hist_sum128(const float *h)
+{
+    float s = warp32_sum(h);
+    s = s + warp32_sum(h + 32);
+    s = s + warp32_sum(h + 64);
+    s = s + warp32_sum(h + 96);
+    return s;
+}
+
+void oracle_descriptor(const float *grad2, int w, int p, int h, const float *dw, int x, int y,
+                       float orientation_deg, float *out)
+{
+    long gDim = (long)p * h;
+    float c32[32], s32[32];
+    oracle_rotation_table(c32, s32);
+    int k = (int)(orientation_deg / 11.25f);
+    float cs = c32[k & 31], sn = s32[k & 31];
+    float wgt[256];
+    int bin[256];
+    for (int ty = 0; ty < 16; ++ty)
+        for (int tx = 0; tx < 16; ++tx) {
+            float dx = (float)tx - 7.5f, dy = (float)ty - 7.5f;
+            float t1 = dx * cs, t2 = dy * sn;
+            float u = t1 + t2;
+            float t3 = dy * cs, t4 = dx * sn;
+            float v = t3 - t4;
+            float px = (float)x + u, py = (float)y + v;
+            float fx = floorf(px), fy = floorf(py);
+            float ax = px - fx, ay = py - fy;
+            int x0 = clampi((int)fx, 0, w - 1), x1 = clampi((int)fx + 1, 0, w - 1);
+            int y0 = clampi((int)fy, 0, h - 1), y1 = clampi((int)fy + 1, 0, h - 1);
+            float val[2];
+            for (int c = 0; c < 2; ++c) {
+                const float *pl = grad2 + c * gDim;
+                float v00 = pl[x0 + (long)p * y0], v10 = pl[x1 + (long)p * y0];
+                float v01 = pl[x0 + (long)p * y1], v11 = pl[x1 + (long)p * y1];
+                float top = lerpf(v00, v10, ax);
+                float bot = lerpf(v01, v11, ax);
+                val[c] = lerpf(top, bot, ay);
+            }
+            float m = val[0] * dw[tx];
+            m = m * dw[ty];
+            wgt[ty * 16 + tx] = m;
+            bin[ty * 16 + tx] = oracle_assign_bin(val[1], 8);
+        }
+    float hist[128];
+    for (int cy = 0; cy < 4; ++cy)
+        for (int cx = 0; cx < 4; ++cx)
+            for (int b = 0; b < 8; ++b) {
+                float s = 0.0f;
+                for (int ty = 4 * cy; ty < 4 * cy + 4; ++ty)
+                    for (int tx = 4 * cx; tx < 4 * cx + 4; ++tx)
+                        if (bin[ty * 16 + tx] == b)
+                            s += wgt[ty * 16 + tx];
+                hist[b + 8 * cx + 32 * cy] = s;
+            }
+    float S1 = hist_sum128(hist);
+    for (int i = 0; i < 128; ++i) {
+        hist[i] /= S1;
+        if ((double)hist[i] > 0.2)
+            hist[i] = (float)0.2;
+    }
+    float S2 = hist_sum128(hist);
+    for (int i = 0; i < 128; ++i)
+        out[i] = hist[i] / S2;
+}
+
+/* ---- extractSift cudaSiftH.cu:9-117 --------------------------------------- */
+int oracle_extract(const OracleParams *pr, const float *img, int w, int pitch, int h, int octave0,
+                   OracleSiftPoint *pts, unsigned char *meta, int *total_found)
+{
+    int S = pr->n_scales;
+    float taps[8 * TAPS], wnd[8 * 16], dwnd[16];
+    oracle_tables(pr, taps, wnd, dwnd);
+    int count = 0, total = 0;
+    const float *src = img;
+    float *owned_src = NULL;
+    int p = pitch;
+    int *xy = (int *)malloc(sizeof(int) * 2 * pr->max_points);
+    for (int o = octave0; o < pr->n_octaves; ++o) {
+        if (count >= pr->max_points) /* cudaSiftH.cu:12-13 */
+            break;
+        long gDim = (long)p * h;
+        float *tmp = (float *)malloc(sizeof(float) * gDim * (S + 3));
+        float *blur = (float *)malloc(sizeof(float) * gDim * (S + 3));
+        float *dog = (float *)malloc(sizeof(float) * gDim * (S + 2));
+        float *hess = (float *)malloc(sizeof(float) * gDim * 3 * S);
+        float *grad = (float *)malloc(sizeof(float) * gDim * 2 * S);
+        /* pad columns [w,p) are never written by the reference: poison them */
+        for (long i = 0; i < gDim * (S + 3); ++i)
+            tmp[i] = blur[i] = NAN;
+        for (long i = 0; i < gDim * (S + 2); ++i)
+            dog[i] = NAN;
+        for (long i = 0; i < gDim * 3 * S; ++i)
+            hess[i] = NAN;
+        for (long i = 0; i < gDim * 2 * S; ++i)
+            grad[i] = NAN;
+        oracle_xblur(pr, src, tmp, w, p, h);
+        oracle_yblur(pr, tmp, blur, w, p, h);
+        oracle_dog(pr, blur, dog, w, p, h);
+        oracle_hessian(pr, blur, hess, w, p, h);
+        oracle_gradient(pr, blur, grad, w, p, h);
+        for (int i = 0; i < S; ++i) { /* computeOctaveSift cudaSiftH.cu:80-116 */
+            if (count >= pr->max_points)
+                break;
+            int room = pr->max_points - count;
+            int n = oracle_find_extrema_closed(pr, dog + i * gDim, hess + (long)i * 3 * gDim, w,
+                                               p, h, xy, room);
+            total += n;
+            if (n > room)
+                n = room; /* clampPtCount cudaSiftH.cu:340-352 */
+            float scale = oracle_scale_value(pr, i, o);
+            const float *g2 = grad + (long)i * 2 * gDim;
+            for (int j = 0; j < n; ++j) {
+                OracleSiftPoint *q = &pts[count + j];
+                q->xpos = (float)xy[2 * j];
+                q->ypos = (float)xy[2 * j + 1];
+                q->scale = scale;
+                q->orientation = oracle_orientation(g2, w, p, h, wnd + i * 16, xy[2 * j],
+                                                    xy[2 * j + 1], NULL);
+                oracle_descriptor(g2, w, p, h, dwnd, xy[2 * j], xy[2 * j + 1], q->orientation,
+                                  q->data);
+                if (meta) {
+                    meta[2 * (count + j)] = (unsigned char)o;
+                    meta[2 * (count + j) + 1] = (unsigned char)i;
+                }
+            }
+            count += n;
+        }
+        float *next = NULL;
+        int w_ = oracle_idivup(w, 2), h_ = oracle_idivup(h, 2), p_ = oracle_ialignup(w_, 128);
+        if (o + 1 < pr->n_octaves) { /* cudaSiftH.cu:40-55 */
+            next = (float *)malloc(sizeof(float) * (long)p_ * h_);
+            for (long i = 0; i < (long)p_ * h_; ++i)
+                next[i] = NAN;
+            oracle_downsample(blur + (long)S * gDim, next, w, p, h);
+        }
+        free(tmp);
+        free(blur);
+        free(dog);
+        free(hess);
+        free(grad);
+        free(owned_src);
+        owned_src = next;
+        src = next;
+        w = w_;
+        h = h_;
+        p = p_;
+    }
+    free(owned_src);
+    free(xy);
+    if (total_found)
+        *total_found = total;
+    return count;
+}
+
+typedef struct {
+    const OracleParams *pr;
+    const float *imgs;
+    long img_stride;
+    int n, w, pitch, h;
+    OracleSiftPoint *pts;
+    int *counts;
+    int next;
+    pthread_mutex_t mu;
+} BatchJob;
+
+static void *batch_worker(void *arg)
+{
+    BatchJob *jb = (BatchJob *)arg;
+    for (;;) {
+        pthread_mutex_lock(&jb->mu);
+        int i = jb->next++;
+        pthread_mutex_unlock(&jb->mu);
+        if (i >= jb->n)
+            break;
+        jb->counts[i] = oracle_extract(jb->pr, jb->imgs + (long)i * jb->img_stride, jb->w,
+                                       jb->pitch, jb->h, 0,
+                                       jb->pts + (long)i * jb->pr->max_points, NULL, NULL);
+    }
+    return NULL;
+}
+
+int oracle_extract_batch(const OracleParams *pr, const float *imgs, long img_stride, int n, int w,
+                         int pitch, int h, OracleSiftPoint *pts, int *counts, int n_threads)
+{
+    BatchJob jb = {pr, imgs, img_stride, n, w, pitch, h, pts, counts, 0, PTHREAD_MUTEX_INITIALIZER};
+    if (n_threads < 1)
+        n_threads = 1;
+    if (n_threads > 256)
+        n_threads = 256;
+    pthread_t th[256];
+    for (int t = 0; t < n_threads; ++t)
+        pthread_create(&th[t], NULL, batch_worker, &jb);
+    for (int t = 0; t < n_threads; ++t)
+        pthread_join(th[t], NULL);
+    return 0;
+}
+
+void oracle_gray_q14(const unsigned char *rgb, int npix, unsigned char *gray)
+{
+    for (int i = 0; i < npix; ++i) {
+        int R = rgb[3 * i], G = rgb[3 * i + 1], B = rgb[3 * i + 2];
+        gray[i] = (unsigned char)((1868 * B + 9617 * G + 4899 * R + 8192) >> 14);
+    }
+}
+
+/* saveSift sift.cu:151-160 */
+long oracle_format_points(const OracleSiftPoint *pts, int n, char *buf, long cap)
+{
+    long off = 0;
+    for (int j = 0; j < n; ++j) {
+        if (cap - off < 4096)
+            return -1;
+        off += sprintf(buf + off, "%.1f\t%.1f\t%.3f\t%.3f\t", pts[j].xpos, pts[j].ypos,
+                       pts[j].scale, pts[j].orientation);
+        for (int k = 0; k < 128; ++k)
+            off += sprintf(buf + off, "%.6f ", pts[j].data[k]);
+        buf[off++] = '\n';
+    }
+    return off;
+}

@@ -1,0 +1,106 @@
+/*
+ * Thin C-ABI layer over the HIP runtime and the gfx950 kernels.  The C host
+ * code (sift_host.c) sees only this header: plain pointers, ints and structs
+ * passed by value.  Implemented in sift_kernels.hip.
+ */
+#ifndef SIFT_HIP_LAYER_H
+#define SIFT_HIP_LAYER_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HL_TAPS 19
+#define HL_HALF_TAPS 10 /* taps are symmetric: c[k] == c[18-k] */
+#define HL_MAX_PLANES 7 /* n_scales + 3, n_scales <= 4 */
+#define HL_MAX_OCT 8
+#define HL_MAX_GROUPS 32 /* (octave, scale) pairs */
+
+/* blur taps folded by symmetry: u[i][m] = c[i*19 + m], m = 0..9 */
+typedef struct {
+    float u[HL_MAX_PLANES][HL_HALF_TAPS];
+} hl_taps;
+
+typedef struct {
+    float *p[HL_MAX_PLANES];
+} hl_plane_ptrs;
+
+/* geometry of one octave inside a per-image arena (offsets in floats) */
+typedef struct {
+    int w, h, p;        /* internal pitch p */
+    long blur_off;      /* S kept blur planes (plane index 1..S) */
+} hl_octave;
+
+typedef struct {
+    int n_scales;
+    int n_groups;            /* octaves processed * n_scales */
+    int first_octave;        /* octave index of group 0 */
+    int cap;                 /* max_points */
+    hl_octave oct[HL_MAX_OCT]; /* indexed by group / n_scales */
+    float scale_value[HL_MAX_GROUPS];
+    float wnd[4 * 16];       /* orientation window per scale index */
+    float desc_wnd[16];
+    float cos32[32], sin32[32];
+} hl_keypoint_args;
+
+/* runtime */
+int hl_device_count(void);
+int hl_set_device(int dev);
+int hl_get_device(void);
+int hl_malloc(void **p, size_t bytes);
+int hl_malloc_pitch(void **p, size_t *pitch_bytes, size_t width_bytes, size_t height);
+int hl_free(void *p);
+int hl_memset_async(void *p, int v, size_t bytes, void *stream);
+int hl_memcpy_async(void *dst, const void *src, size_t bytes, int kind, void *stream); /* 1 h2d 2 d2h 3 d2d */
+int hl_memcpy2d_async(void *dst, size_t dpitch, const void *src, size_t spitch, size_t wbytes,
+                      size_t h, int kind, void *stream);
+int hl_stream_create(void **s);
+int hl_stream_destroy(void *s);
+int hl_stream_sync(void *s);
+int hl_device_sync(void);
+int hl_host_alloc(void **p, size_t bytes);
+int hl_host_free(void *p);
+const char *hl_error_string(int code);
+
+/* timing */
+void hl_timing_enable(int on);
+int hl_timing_read(int kernel, double *ms, long *launches);
+void hl_timing_reset(void);
+
+/* kernels.  nimg images per launch; image z of a buffer at base + z*stride. */
+int hl_row_blur(const float *src, int src_pitch, long src_stride, float *tmp, long tmp_stride,
+                int w, int p, int h, int n_scales, int nimg, const hl_taps *taps, void *stream);
+/* blur_out: per-plane destination (NULL = not stored); dog: S+2 planes or NULL;
+ * next_base: even pixels of plane S with pitch next_p, or NULL */
+int hl_col_blur_dog(const float *tmp, long tmp_stride, const hl_plane_ptrs *blur_out,
+                    long blur_stride, float *dog, long dog_stride, float *next_base,
+                    long next_stride, int next_p, int w, int p, int h, int n_scales, int nimg,
+                    const hl_taps *taps, void *stream);
+/* appends (x | y<<16) of accepted pixels of scales 0..S-1 to
+ * cand + (group0+i)*cap, counting in counts[group0+i] */
+int hl_detect(const float *dog, long dog_stride, const float *blur, long blur_stride, int w,
+              int p, int h, int n_scales, float r_thresh, float extrema_thresh,
+              unsigned *cand, long cand_stride, unsigned *counts, long counts_stride,
+              int group0, int cap, int nimg, void *stream);
+/* orientation + descriptor for every candidate; writes SiftPoint records
+ * behind base_count[z] and meta (may be NULL) */
+int hl_keypoints(void *pts, long pts_stride_points, unsigned char *meta, const float *arena,
+                 long arena_stride, const unsigned *cand, long cand_stride,
+                 const unsigned *counts, long counts_stride, const unsigned *base_count,
+                 const hl_keypoint_args *args, int nimg, void *stream);
+/* base_count[z] = min(base_count[z] + sum(min(counts, cap)), cap) */
+int hl_finalize_counts(unsigned *base_count, const unsigned *counts, long counts_stride,
+                       int n_groups, int cap, int nimg, void *stream);
+
+/* dense stage kernels */
+int hl_subtract(float *dst, const float *a, const float *b, int w, int p, int h, void *stream);
+int hl_hessian(float *dst, const float *src, int w, int p, int h, void *stream);
+int hl_gradient(float *dst, const float *src, int w, int p, int h, void *stream);
+int hl_copy(float *dst, const float *src, int w, int p, int h, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

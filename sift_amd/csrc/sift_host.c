@@ -1,0 +1,666 @@
+/*
+ * C host side of the MI355X SIFT extractor: configuration, Gaussian tables,
+ * scratch arenas, the octave loop and the entry points of include/sift_amd.h.
+ * Talks to the GPU only through the C-ABI layer in hip_layer.h.
+ *
+ * Reference counterpart: Sift/src/cudaSiftH.cu (host driver) and the table
+ * construction in Sift/src/utils.cc:41-53.
+ */
+#include "../../include/sift_amd.h"
+#include "hip_layer.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define REF_PI 3.14159265 /* utils.h:4 */
+#define MAX_DEV 16
+#define BATCH_SLOT SIFT_MAX_SLOTS
+
+/* ---- state ---------------------------------------------------------------- */
+typedef struct {
+    int valid;
+    /* signature the arena was planned for */
+    int w, h, S, O, oct0, cap, nimg;
+    float *arena;
+    long arena_stride; /* floats per image */
+    long tmp_off, dog_off;
+    long base_off[SIFT_MAX_OCTAVES];
+    int ow[SIFT_MAX_OCTAVES], oh[SIFT_MAX_OCTAVES], op[SIFT_MAX_OCTAVES];
+    long blur_off[SIFT_MAX_OCTAVES];
+    unsigned *counts; /* nimg * HL_MAX_GROUPS */
+    unsigned *cand;   /* nimg * groups * cap */
+    long cand_stride;
+    unsigned *base_count; /* batch slot only: one word per image of the batch */
+    int base_count_n;
+    void *last_stream;
+} slot_ctx;
+
+static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
+static sift_params g_params = {4, 2, 2500, 1.6f, 10.0f, 10.0f};
+static int g_tables_ready = 0;
+static float g_blur[HL_MAX_PLANES * HL_TAPS];
+static float g_wnd[4 * 16];
+static float g_desc[16];
+static float g_cos32[32], g_sin32[32];
+static hl_taps g_taps;
+static slot_ctx g_slots[MAX_DEV][SIFT_MAX_SLOTS + 1];
+static unsigned *g_slot_counter[MAX_DEV]; /* device, SIFT_MAX_SLOTS words */
+static int g_chunk = 8;
+static char g_err[512] = "";
+
+static void set_err(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+const char *sift_last_error(void) { return g_err; }
+void sift_clear_error(void) { g_err[0] = 0; }
+
+static int fail_hl(int code, const char *what)
+{
+    if (code <= -1000)
+        set_err("%s: invalid launch arguments (%d)", what, code);
+    else
+        set_err("%s: %s", what, hl_error_string(code));
+    return code;
+}
+
+static int idivup(int a, int b) { return (a % b != 0) ? (a / b + 1) : (a / b); }      /* utils.cc:59 */
+static int ialignup(int A, int a) { return (A % a != 0) ? (A + a - A % a) : A; }     /* utils.cc:60 */
+static long lalign(long v, long a) { return (v + a - 1) / a * a; }
+
+/* ---- tables ---------------------------------------------------------------
+ * utils.cc:41-53: the density is evaluated in double, stored as float, summed
+ * in float and normalised by a float division. */
+static void gaussian1D(float *taps, float sigma, int n)
+{
+    float sum = 0;
+    const float centre = (float)(n - 1) / 2;
+    for (int i = 0; i < n; ++i) {
+        const float d = (float)i - centre;
+        const double amp = 1 / (pow(2.0f * REF_PI, (double)0.5f) * (double)sigma);
+        const double arg = -pow((double)d, 2) / (2 * pow((double)sigma, 2));
+        taps[i] = (float)(amp * exp(arg));
+        sum += taps[i];
+    }
+    for (int i = 0; i < n; ++i)
+        taps[i] /= sum;
+}
+
+static int build_tables(void)
+{
+    const int S = g_params.n_scales;
+    const float k = (float)pow(2, 0.5); /* cudaSiftH.cu:131 */
+    for (int i = 0; i < S + 3; ++i) {   /* cudaSiftH.cu:135-139 */
+        const float s = (float)(pow((double)k, (double)(i - 1)) * (double)g_params.sigma);
+        gaussian1D(g_blur + i * HL_TAPS, s, HL_TAPS);
+    }
+    for (int i = 0; i < S; ++i) { /* cudaSiftH.cu:145-149 */
+        const float s = (float)(pow((double)k, (double)i) * (double)g_params.sigma * 1.5);
+        gaussian1D(g_wnd + i * 16, s, 16);
+    }
+    gaussian1D(g_desc, (float)((double)g_params.sigma * 1.5), 16); /* cudaSiftH.cu:153-155 */
+    for (int i = 0; i < S + 3; ++i)
+        for (int m = 0; m < HL_HALF_TAPS; ++m) {
+            if (g_blur[i * HL_TAPS + m] != g_blur[i * HL_TAPS + 18 - m]) {
+                set_err("blur taps of plane %d are not symmetric", i);
+                return -1;
+            }
+            g_taps.u[i][m] = g_blur[i * HL_TAPS + m];
+        }
+    for (int q = 0; q < 32; ++q) { /* the 32 orientations the detector can assign */
+        const double rad = (double)(11.25f * (float)q) * (3.14159265358979323846 / 180.0);
+        g_cos32[q] = (float)cos(rad);
+        g_sin32[q] = (float)sin(rad);
+    }
+    g_tables_ready = 1;
+    return 0;
+}
+
+static float scale_value(int i, int octave) /* cudaSiftH.cu:94-95 */
+{
+    const float k = (float)pow(2, 0.5);
+    return (float)(pow((double)k, (double)(i + g_params.n_scales * octave)) * (double)g_params.sigma);
+}
+
+void sift_default_params(sift_params *p)
+{
+    p->n_octaves = 4;
+    p->n_scales = 2;
+    p->max_points = 2500;
+    p->sigma = 1.6f;
+    p->r_thresh = 10.0f;
+    p->extrema_thresh = 10.0f;
+}
+
+int sift_set_params(const sift_params *p)
+{
+    if (p->n_octaves < 1 || p->n_octaves > SIFT_MAX_OCTAVES) {
+        set_err("n_octaves %d outside 1..%d", p->n_octaves, SIFT_MAX_OCTAVES);
+        return -1;
+    }
+    if (p->n_scales != 2 && p->n_scales != 3) {
+        set_err("n_scales %d: kernels are built for 2 and 3", p->n_scales);
+        return -1;
+    }
+    if (p->max_points < 1 || p->max_points > (1 << 22)) {
+        set_err("max_points %d outside 1..2^22", p->max_points);
+        return -1;
+    }
+    if (!(p->sigma > 0.f) || !(p->r_thresh > 0.f)) {
+        set_err("sigma and r_thresh must be positive");
+        return -1;
+    }
+    pthread_mutex_lock(&g_mu);
+    g_params = *p;
+    int r = build_tables();
+    pthread_mutex_unlock(&g_mu);
+    return r;
+}
+
+void sift_get_params(sift_params *p) { *p = g_params; }
+
+void sift_get_tables(float *blur, float *wnd, float *desc)
+{
+    if (!g_tables_ready)
+        build_tables();
+    memcpy(blur, g_blur, sizeof(float) * (g_params.n_scales + 3) * HL_TAPS);
+    memcpy(wnd, g_wnd, sizeof(float) * g_params.n_scales * 16);
+    memcpy(desc, g_desc, sizeof(float) * 16);
+}
+
+void sift_set_batch_chunk(int n)
+{
+    if (n >= 1 && n <= 1024)
+        g_chunk = n;
+}
+
+/* ---- arenas --------------------------------------------------------------- */
+static void free_slot(slot_ctx *c)
+{
+    if (c->arena) hl_free(c->arena);
+    if (c->counts) hl_free(c->counts);
+    if (c->cand) hl_free(c->cand);
+    if (c->base_count) hl_free(c->base_count);
+    memset(c, 0, sizeof *c);
+}
+
+void sift_shutdown(void)
+{
+    pthread_mutex_lock(&g_mu);
+    int dev = hl_get_device();
+    if (dev >= 0 && dev < MAX_DEV) {
+        hl_device_sync();
+        for (int s = 0; s <= SIFT_MAX_SLOTS; ++s)
+            free_slot(&g_slots[dev][s]);
+        if (g_slot_counter[dev]) {
+            hl_free(g_slot_counter[dev]);
+            g_slot_counter[dev] = NULL;
+        }
+    }
+    pthread_mutex_unlock(&g_mu);
+}
+
+static int ensure_slot_counter(int dev)
+{
+    if (g_slot_counter[dev])
+        return 0;
+    void *p = NULL;
+    int r = hl_malloc(&p, sizeof(unsigned) * SIFT_MAX_SLOTS);
+    if (r) return fail_hl(r, "allocating slot counters");
+    r = hl_memset_async(p, 0, sizeof(unsigned) * SIFT_MAX_SLOTS, NULL);
+    if (!r) r = hl_stream_sync(NULL);
+    if (r) return fail_hl(r, "zeroing slot counters");
+    g_slot_counter[dev] = (unsigned *)p;
+    return 0;
+}
+
+/* Plans (or re-plans) the per-image arena: first-octave sized row-pass and DoG
+ * scratch shared by all octaves, S kept blur planes per octave (planes 1..S:
+ * the Hessian, the gradients and the next octave read nothing else), and the
+ * down-sampled base of every later octave. */
+static int ensure_arena(slot_ctx *c, int w, int h, int oct0, int nimg)
+{
+    const int S = g_params.n_scales, O = g_params.n_octaves, cap = g_params.max_points;
+    if (c->valid && c->w == w && c->h == h && c->S == S && c->O == O && c->oct0 == oct0 &&
+        c->cap == cap && c->nimg >= nimg)
+        return 0;
+    if (c->valid) { /* geometry changed: drain the slot before its memory goes away */
+        int r = hl_stream_sync(c->last_stream);
+        if (r) return fail_hl(r, "draining slot");
+    }
+    unsigned *keep_base = c->base_count;
+    int keep_n = c->base_count_n;
+    c->base_count = NULL;
+    free_slot(c);
+    c->base_count = keep_base;
+    c->base_count_n = keep_n;
+
+    long off = 0;
+    int ww = w, hh = h;
+    const int p0 = ialignup(w, 64);
+    c->tmp_off = off;
+    off += lalign((long)p0 * h * (S + 3), 64);
+    c->dog_off = off;
+    off += lalign((long)p0 * h * (S + 2), 64);
+    for (int o = oct0; o < O; ++o) {
+        const int oi = o - oct0;
+        c->ow[oi] = ww;
+        c->oh[oi] = hh;
+        c->op[oi] = (o == oct0) ? p0 : ialignup(ww, 128); /* cudaSiftH.cu:46 */
+        c->blur_off[oi] = off;
+        off += lalign((long)c->op[oi] * hh * S, 64);
+        if (o > oct0) {
+            c->base_off[oi] = off;
+            off += lalign((long)c->op[oi] * hh, 64);
+        }
+        ww = idivup(ww, 2); /* cudaSiftH.cu:44-45 */
+        hh = idivup(hh, 2);
+    }
+    c->arena_stride = off;
+    const int groups = (O - oct0) * S;
+    void *p = NULL;
+    int r = hl_malloc(&p, sizeof(float) * (size_t)off * nimg);
+    if (r) return fail_hl(r, "allocating arena");
+    c->arena = (float *)p;
+    r = hl_malloc(&p, sizeof(unsigned) * HL_MAX_GROUPS * (size_t)nimg);
+    if (r) return fail_hl(r, "allocating group counters");
+    c->counts = (unsigned *)p;
+    c->cand_stride = (long)groups * cap;
+    r = hl_malloc(&p, sizeof(unsigned) * (size_t)c->cand_stride * nimg);
+    if (r) return fail_hl(r, "allocating candidate lists");
+    c->cand = (unsigned *)p;
+    c->w = w;
+    c->h = h;
+    c->S = S;
+    c->O = O;
+    c->oct0 = oct0;
+    c->cap = cap;
+    c->nimg = nimg;
+    c->valid = 1;
+    return 0;
+}
+
+/* Enqueues the whole path for nimg images of one geometry on `stream`.
+ * cudaSiftH.cu:9-117 does this per image with a recursion, 12 allocations and
+ * a dozen blocking copies per octave; here the octaves are a loop over a
+ * preplanned arena and nothing blocks. */
+static int enqueue_extract(slot_ctx *c, SiftPoint *pts, unsigned char *meta, const float *imgs,
+                           long img_stride, int nimg, int w, int pitch, int h, int oct0,
+                           unsigned *base_count, void *stream)
+{
+    const int S = g_params.n_scales, O = g_params.n_octaves, cap = g_params.max_points;
+    int r = hl_memset_async(c->counts, 0, sizeof(unsigned) * HL_MAX_GROUPS * nimg, stream);
+    if (r) return fail_hl(r, "resetting group counters");
+    float *A = c->arena;
+    const long AS = c->arena_stride;
+    for (int o = oct0; o < O; ++o) {
+        const int oi = o - oct0;
+        const int ww = c->ow[oi], hh = c->oh[oi], pp = c->op[oi];
+        const long plane = (long)pp * hh;
+        if (o == oct0)
+            r = hl_row_blur(imgs, pitch, img_stride, A + c->tmp_off, AS, ww, pp, hh, S, nimg,
+                            &g_taps, stream);
+        else
+            r = hl_row_blur(A + c->base_off[oi], pp, AS, A + c->tmp_off, AS, ww, pp, hh, S, nimg,
+                            &g_taps, stream);
+        if (r) return fail_hl(r, "row blur");
+        hl_plane_ptrs bo;
+        memset(&bo, 0, sizeof bo);
+        for (int i = 1; i <= S; ++i)
+            bo.p[i] = A + c->blur_off[oi] + (long)(i - 1) * plane;
+        float *next = (o + 1 < O) ? A + c->base_off[oi + 1] : NULL;
+        const int next_p = (o + 1 < O) ? c->op[oi + 1] : 0;
+        r = hl_col_blur_dog(A + c->tmp_off, AS, &bo, AS, A + c->dog_off, AS, next, AS, next_p, ww,
+                            pp, hh, S, nimg, &g_taps, stream);
+        if (r) return fail_hl(r, "column blur");
+        r = hl_detect(A + c->dog_off, AS, A + c->blur_off[oi], AS, ww, pp, hh, S, g_params.r_thresh,
+                      g_params.extrema_thresh, c->cand, c->cand_stride, c->counts, HL_MAX_GROUPS,
+                      oi * S, cap, nimg, stream);
+        if (r) return fail_hl(r, "detection");
+    }
+    hl_keypoint_args ka;
+    memset(&ka, 0, sizeof ka);
+    ka.n_scales = S;
+    ka.n_groups = (O - oct0) * S;
+    ka.first_octave = oct0;
+    ka.cap = cap;
+    for (int o = oct0; o < O; ++o) {
+        const int oi = o - oct0;
+        ka.oct[oi].w = c->ow[oi];
+        ka.oct[oi].h = c->oh[oi];
+        ka.oct[oi].p = c->op[oi];
+        ka.oct[oi].blur_off = c->blur_off[oi];
+        for (int i = 0; i < S; ++i)
+            ka.scale_value[oi * S + i] = scale_value(i, o);
+    }
+    memcpy(ka.wnd, g_wnd, sizeof(float) * S * 16);
+    memcpy(ka.desc_wnd, g_desc, sizeof g_desc);
+    memcpy(ka.cos32, g_cos32, sizeof g_cos32);
+    memcpy(ka.sin32, g_sin32, sizeof g_sin32);
+    r = hl_keypoints(pts, cap, meta, A, AS, c->cand, c->cand_stride, c->counts, HL_MAX_GROUPS,
+                     base_count, &ka, nimg, stream);
+    if (r) return fail_hl(r, "keypoint kernel");
+    r = hl_finalize_counts(base_count, c->counts, HL_MAX_GROUPS, ka.n_groups, cap, nimg, stream);
+    if (r) return fail_hl(r, "count update");
+    c->last_stream = stream;
+    return 0;
+}
+
+/* ---- reference entry points ------------------------------------------------ */
+void initDeviceConstant(void)
+{
+    pthread_mutex_lock(&g_mu);
+    build_tables();
+    pthread_mutex_unlock(&g_mu);
+}
+
+void initDeviceVariables(void)
+{
+    pthread_mutex_lock(&g_mu);
+    int dev = hl_get_device();
+    if (dev < 0 || dev >= MAX_DEV) {
+        set_err("no usable HIP device");
+    } else if (ensure_slot_counter(dev) == 0) {
+        /* the reference's cudaMemcpyToSymbol is ordered after all earlier work */
+        int r = hl_device_sync();
+        if (!r) r = hl_memset_async(g_slot_counter[dev], 0, sizeof(unsigned) * SIFT_MAX_SLOTS, NULL);
+        if (!r) r = hl_stream_sync(NULL);
+        if (r) fail_hl(r, "initDeviceVariables");
+    }
+    pthread_mutex_unlock(&g_mu);
+}
+
+void extractSift(SiftPoint *siftPt, float *d_src, int width, int pitch, int height, void *stream,
+                 int streamIdx, int octaveIdx)
+{
+    pthread_mutex_lock(&g_mu);
+    do {
+        if (!g_tables_ready && build_tables())
+            break;
+        if (!siftPt || !d_src || width < 1 || height < 1 || pitch < width) {
+            set_err("extractSift: bad image arguments (w=%d pitch=%d h=%d)", width, pitch, height);
+            break;
+        }
+        if (width > 65535 || height > 65535) {
+            set_err("extractSift: image larger than 65535 pixels on a side");
+            break;
+        }
+        if (streamIdx < 0 || streamIdx >= SIFT_MAX_SLOTS) {
+            set_err("extractSift: streamIdx %d outside 0..%d", streamIdx, SIFT_MAX_SLOTS - 1);
+            break;
+        }
+        if (octaveIdx < 0 || octaveIdx >= g_params.n_octaves) /* cudaSiftH.cu:41: nothing to do */
+            break;
+        int dev = hl_get_device();
+        if (dev < 0 || dev >= MAX_DEV) {
+            set_err("extractSift: no usable HIP device");
+            break;
+        }
+        if (ensure_slot_counter(dev))
+            break;
+        slot_ctx *c = &g_slots[dev][streamIdx];
+        if (ensure_arena(c, width, height, octaveIdx, 1))
+            break;
+        enqueue_extract(c, siftPt, NULL, d_src, 0, 1, width, pitch, height, octaveIdx,
+                        g_slot_counter[dev] + streamIdx, stream);
+    } while (0);
+    pthread_mutex_unlock(&g_mu);
+}
+
+int getPointCount(int streamIdx)
+{
+    int result = -1;
+    pthread_mutex_lock(&g_mu);
+    do {
+        if (streamIdx < 0 || streamIdx >= SIFT_MAX_SLOTS) {
+            set_err("getPointCount: streamIdx %d outside 0..%d", streamIdx, SIFT_MAX_SLOTS - 1);
+            break;
+        }
+        int dev = hl_get_device();
+        if (dev < 0 || dev >= MAX_DEV) {
+            set_err("getPointCount: no usable HIP device");
+            break;
+        }
+        if (ensure_slot_counter(dev))
+            break;
+        slot_ctx *c = &g_slots[dev][streamIdx];
+        int r = 0;
+        if (c->valid) r = hl_stream_sync(c->last_stream);
+        unsigned v = 0;
+        if (!r) r = hl_memcpy_async(&v, g_slot_counter[dev] + streamIdx, sizeof v, 2, NULL);
+        if (!r) r = hl_stream_sync(NULL);
+        if (r) {
+            fail_hl(r, "getPointCount");
+            break;
+        }
+        result = (int)v;
+    } while (0);
+    pthread_mutex_unlock(&g_mu);
+    return result;
+}
+
+/* ---- batch ------------------------------------------------------------------ */
+int sift_extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts, const float *d_imgs,
+                       long img_stride, int n, int width, int pitch, int height, void *stream)
+{
+    int rc = -1;
+    pthread_mutex_lock(&g_mu);
+    do {
+        if (!g_tables_ready && build_tables())
+            break;
+        if (!d_pts || !d_imgs || !h_counts || n < 1 || width < 1 || height < 1 || pitch < width ||
+            img_stride < (long)pitch * (height - 1) + width) {
+            set_err("sift_extract_batch: bad arguments");
+            break;
+        }
+        if (width > 65535 || height > 65535) {
+            set_err("sift_extract_batch: image larger than 65535 pixels on a side");
+            break;
+        }
+        int dev = hl_get_device();
+        if (dev < 0 || dev >= MAX_DEV) {
+            set_err("sift_extract_batch: no usable HIP device");
+            break;
+        }
+        slot_ctx *c = &g_slots[dev][BATCH_SLOT];
+        const int chunk = n < g_chunk ? n : g_chunk;
+        if (ensure_arena(c, width, height, 0, chunk))
+            break;
+        if (c->base_count_n < n) {
+            if (c->base_count) {
+                hl_stream_sync(c->last_stream);
+                hl_free(c->base_count);
+                c->base_count = NULL;
+            }
+            void *p = NULL;
+            int r = hl_malloc(&p, sizeof(unsigned) * (size_t)n);
+            if (r) {
+                fail_hl(r, "allocating batch counters");
+                break;
+            }
+            c->base_count = (unsigned *)p;
+            c->base_count_n = n;
+        }
+        int r = hl_memset_async(c->base_count, 0, sizeof(unsigned) * (size_t)n, stream);
+        if (r) {
+            fail_hl(r, "zeroing batch counters");
+            break;
+        }
+        const int cap = g_params.max_points;
+        int bad = 0;
+        for (int i0 = 0; i0 < n && !bad; i0 += chunk) {
+            const int m = (n - i0) < chunk ? (n - i0) : chunk;
+            bad = enqueue_extract(c, d_pts + (long)i0 * cap, d_meta ? d_meta + 2L * i0 * cap : NULL,
+                                  d_imgs + (long)i0 * img_stride, img_stride, m, width, pitch,
+                                  height, 0, c->base_count + i0, stream);
+        }
+        if (bad)
+            break;
+        r = hl_memcpy_async(h_counts, c->base_count, sizeof(unsigned) * (size_t)n, 2, stream);
+        if (!r) r = hl_stream_sync(stream);
+        if (r) {
+            fail_hl(r, "reading batch counters");
+            break;
+        }
+        rc = 0;
+    } while (0);
+    pthread_mutex_unlock(&g_mu);
+    return rc;
+}
+
+/* ---- stage launchers (dense planes, reference layout) ------------------------ */
+static int stage_ok(const char *name, const void *a, const void *b, int w, int p, int h)
+{
+    if (!g_tables_ready && build_tables())
+        return 0;
+    if (!a || !b || w < 1 || h < 1 || p < w) {
+        set_err("%s: bad arguments (w=%d pitch=%d h=%d)", name, w, p, h);
+        return 0;
+    }
+    return 1;
+}
+
+void blurOctave(float *dst, float *src, int width, int pitch, int height, void *stream)
+{
+    if (!stage_ok("blurOctave", dst, src, width, pitch, height))
+        return;
+    if (pitch & 3) {
+        set_err("blurOctave: pitch must be a multiple of 4 floats");
+        return;
+    }
+    const int S = g_params.n_scales;
+    const long plane = (long)pitch * height;
+    void *tmp = NULL;
+    int r = hl_malloc(&tmp, sizeof(float) * (size_t)plane * (S + 3));
+    if (r) {
+        fail_hl(r, "blurOctave scratch");
+        return;
+    }
+    r = hl_row_blur(src, pitch, 0, (float *)tmp, 0, width, pitch, height, S, 1, &g_taps, stream);
+    if (r) fail_hl(r, "blurOctave row pass");
+    hl_plane_ptrs bo;
+    memset(&bo, 0, sizeof bo);
+    for (int i = 0; i < S + 3; ++i)
+        bo.p[i] = dst + i * plane;
+    if (!r) {
+        r = hl_col_blur_dog((const float *)tmp, 0, &bo, 0, NULL, 0, NULL, 0, 0, width, pitch,
+                            height, S, 1, &g_taps, stream);
+        if (r) fail_hl(r, "blurOctave column pass");
+    }
+    hl_stream_sync(stream); /* the scratch is freed here, as cudaSiftH.cu:258 does */
+    hl_free(tmp);
+}
+
+void computeDiffOfGauss(float *dst, float *src, int width, int pitch, int height, void *stream)
+{
+    if (!stage_ok("computeDiffOfGauss", dst, src, width, pitch, height))
+        return;
+    const long plane = (long)pitch * height;
+    for (int i = 0; i < g_params.n_scales + 2; ++i) { /* cudaSiftH.cu:314-315 */
+        int r = hl_subtract(dst + i * plane, src + i * plane, src + (i + 1) * plane, width, pitch,
+                            height, stream);
+        if (r) {
+            fail_hl(r, "computeDiffOfGauss");
+            return;
+        }
+    }
+}
+
+void computeHessian(float *dst, float *src, int width, int pitch, int height, void *stream)
+{
+    if (!stage_ok("computeHessian", dst, src, width, pitch, height))
+        return;
+    const long plane = (long)pitch * height;
+    for (int i = 0; i < g_params.n_scales; ++i) { /* cudaSiftH.cu:277-282 */
+        int r = hl_hessian(dst + 3L * i * plane, src + (i + 1) * plane, width, pitch, height, stream);
+        if (r) {
+            fail_hl(r, "computeHessian");
+            return;
+        }
+    }
+}
+
+void computeGradient(float *dst, float *src, int width, int pitch, int height, void *stream)
+{
+    if (!stage_ok("computeGradient", dst, src, width, pitch, height))
+        return;
+    const long plane = (long)pitch * height;
+    for (int i = 0; i < g_params.n_scales; ++i) { /* cudaSiftH.cu:299-304 */
+        int r = hl_gradient(dst + 2L * i * plane, src + (i + 1) * plane, width, pitch, height, stream);
+        if (r) {
+            fail_hl(r, "computeGradient");
+            return;
+        }
+    }
+}
+
+void copyDeviceData(float *dst, float *src, int width, int pitch, int height, void *stream)
+{
+    if (!stage_ok("copyDeviceData", dst, src, width, pitch, height))
+        return;
+    int r = hl_copy(dst, src, width, pitch, height, stream);
+    if (r) fail_hl(r, "copyDeviceData");
+}
+
+/* ---- thin device layer ---------------------------------------------------------- */
+#define WRAP(call, what)            \
+    do {                            \
+        int r_ = (call);            \
+        if (r_) fail_hl(r_, what);  \
+        return r_;                  \
+    } while (0)
+
+int sift_device_count(void) { return hl_device_count(); }
+int sift_set_device(int dev) { WRAP(hl_set_device(dev), "sift_set_device"); }
+int sift_dev_malloc(void **p, size_t bytes) { WRAP(hl_malloc(p, bytes), "sift_dev_malloc"); }
+int sift_dev_malloc_pitch(float **p, int *pitch_floats, int width, int height)
+{
+    size_t pb = 0;
+    void *q = NULL;
+    int r = hl_malloc_pitch(&q, &pb, sizeof(float) * (size_t)width, (size_t)height);
+    if (r) return fail_hl(r, "sift_dev_malloc_pitch");
+    *p = (float *)q;
+    *pitch_floats = (int)(pb / sizeof(float)); /* cudaImage.cu:32 */
+    return 0;
+}
+int sift_dev_free(void *p) { WRAP(hl_free(p), "sift_dev_free"); }
+int sift_memcpy2d_h2d_async(float *d, int dp, const float *h, int hp, int w, int ht, void *s)
+{
+    WRAP(hl_memcpy2d_async(d, sizeof(float) * (size_t)dp, h, sizeof(float) * (size_t)hp,
+                           sizeof(float) * (size_t)w, (size_t)ht, 1, s),
+         "sift_memcpy2d_h2d_async");
+}
+int sift_memcpy2d_d2h_async(float *h, int hp, const float *d, int dp, int w, int ht, void *s)
+{
+    WRAP(hl_memcpy2d_async(h, sizeof(float) * (size_t)hp, d, sizeof(float) * (size_t)dp,
+                           sizeof(float) * (size_t)w, (size_t)ht, 2, s),
+         "sift_memcpy2d_d2h_async");
+}
+int sift_memcpy_h2d_async(void *d, const void *h, size_t n, void *s)
+{
+    WRAP(hl_memcpy_async(d, h, n, 1, s), "sift_memcpy_h2d_async");
+}
+int sift_memcpy_d2h_async(void *h, const void *d, size_t n, void *s)
+{
+    WRAP(hl_memcpy_async(h, d, n, 2, s), "sift_memcpy_d2h_async");
+}
+int sift_stream_create(void **s) { WRAP(hl_stream_create(s), "sift_stream_create"); }
+int sift_stream_destroy(void *s) { WRAP(hl_stream_destroy(s), "sift_stream_destroy"); }
+int sift_stream_sync(void *s) { WRAP(hl_stream_sync(s), "sift_stream_sync"); }
+int sift_host_alloc_pinned(void **p, size_t n) { WRAP(hl_host_alloc(p, n), "sift_host_alloc_pinned"); }
+int sift_host_free_pinned(void *p) { WRAP(hl_host_free(p), "sift_host_free_pinned"); }
+
+void sift_timing_enable(int on) { hl_timing_enable(on); }
+int sift_timing_read(int kernel, double *ms, long *launches)
+{
+    return hl_timing_read(kernel, ms, launches);
+}
+void sift_timing_reset(void) { hl_timing_reset(); }

@@ -1,0 +1,881 @@
+// gfx950 kernels of the SIFT path and the thin C-ABI layer over the HIP runtime.
+//
+// Build with -ffp-contract=off: results must be bit-identical to a CPU
+// evaluation of the same arithmetic, so the only fused operations are the
+// explicit fmaf()/fma() calls.
+//
+// Kernels (reference counterpart in Sift/src/excludes/cudaSiftD.cu):
+//   row_blur_kernel      xblurMultiKernel :430-486 + tile loader cudaSiftD.h:43-78
+//   col_blur_dog_kernel  yblurKernel :488-534 + subtractKernel :5-15 + resizeKernel :544-559
+//   detect_kernel        findExtremaKernel :216-305 (+ hessianKernel :366-428 at candidates)
+//   keypoint_kernel      gradientKernel :306-364 (in patch) + OrientationKernel :17-94
+//                        + DescriptorKernel :96-214
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <vector>
+
+#include "hip_layer.h"
+
+namespace {
+
+constexpr int TAPS = HL_TAPS;
+constexpr int RADIUS = 9;
+
+__device__ __forceinline__ float tap(const hl_taps &t, int plane, int k)
+{
+    return t.u[plane][k <= 9 ? k : 18 - k];
+}
+
+// ---------------------------------------------------------------------------
+// Row pass.  One wave per image row segment of 256 pixels: the segment plus a
+// 12-pixel apron on each side is staged once in LDS as 70 float4 (zero outside
+// the image), each lane then holds 28 consecutive inputs in registers and
+// produces 4 consecutive pixels of every plane: out_i[x] = chain over k
+// ascending of fmaf(c_i[k], src[x-9+k], sum), sum0 = 0.
+// ---------------------------------------------------------------------------
+template <int NP, bool ALIGNED>
+__global__ __launch_bounds__(256) void row_blur_kernel(const float *__restrict__ src, int src_pitch,
+                                                       long src_stride, float *__restrict__ tmp,
+                                                       long tmp_stride, int w, int p, int h,
+                                                       hl_taps taps)
+{
+    __shared__ float4 lds[4][72];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int y = blockIdx.y * 4 + wave;
+    const int x0 = blockIdx.x * 256;
+    const bool row_ok = y < h;
+    const float *srow = src + (long)blockIdx.z * src_stride + (long)(row_ok ? y : 0) * src_pitch;
+
+    for (int j = lane; j < 70; j += 64) {
+        const int xs = x0 - 12 + 4 * j;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row_ok && xs >= 0 && xs < w) {
+            if (ALIGNED) {
+                v = *reinterpret_cast<const float4 *>(srow + xs);
+                if (xs + 1 >= w) v.y = 0.f;
+                if (xs + 2 >= w) v.z = 0.f;
+                if (xs + 3 >= w) v.w = 0.f;
+            } else {
+                v.x = srow[xs];
+                if (xs + 1 < w) v.y = srow[xs + 1];
+                if (xs + 2 < w) v.z = srow[xs + 2];
+                if (xs + 3 < w) v.w = srow[xs + 3];
+            }
+        }
+        lds[wave][j] = v;
+    }
+    __syncthreads();
+
+    const int x = x0 + 4 * lane;
+    if (!row_ok || x >= w) return;
+
+    float in[28];
+#pragma unroll
+    for (int m = 0; m < 7; ++m) {
+        const float4 v = lds[wave][lane + m];
+        in[4 * m + 0] = v.x;
+        in[4 * m + 1] = v.y;
+        in[4 * m + 2] = v.z;
+        in[4 * m + 3] = v.w;
+    }
+    float *orow = tmp + (long)blockIdx.z * tmp_stride + (long)y * p + x;
+    const long plane = (long)p * h;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        float o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < TAPS; ++k) sum = __builtin_fmaf(tap(taps, i, k), in[q + 3 + k], sum);
+            o[q] = sum;
+        }
+        *reinterpret_cast<float4 *>(orow + i * plane) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Column pass with fused DoG and down-sampling.  One lane per column, a wave
+// covers 64 consecutive columns (256-byte coalesced rows) and walks down a
+// strip of rows.  Each input row r is loaded once and scattered into the 19
+// partial sums it belongs to: out[yo] accumulates fmaf(c[k], in[yo-9+k], .)
+// with k ascending as the input row ascends, which is exactly the reference's
+// chain order.  The 19 live sums per plane sit in a register ring whose slot
+// index is static because the row loop is unrolled by 19.
+// ---------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(256) void col_blur_dog_kernel(
+    const float *__restrict__ tmp, long tmp_stride, hl_plane_ptrs blur_out, long blur_stride,
+    float *__restrict__ dog, long dog_stride, float *__restrict__ next_base, long next_stride,
+    int next_p, int w, int p, int h, int rows, hl_taps taps)
+{
+    constexpr int NP = S + 3;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= w) return;
+    const int y0 = blockIdx.y * rows;
+    const int y1 = min(y0 + rows, h);
+    const int nin = (y1 - y0) + 2 * RADIUS;
+    const long plane = (long)p * h;
+    const int z = blockIdx.z;
+    const float *tin = tmp + z * tmp_stride + x;
+    float *dg = dog ? dog + z * dog_stride + x : nullptr;
+    float *nb = (next_base && !(x & 1)) ? next_base + z * next_stride + (x >> 1) : nullptr;
+
+    float acc[NP][TAPS];
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) acc[i][k] = 0.f;
+
+    for (int rb = 0; rb < nin; rb += TAPS) {
+#pragma unroll
+        for (int rr = 0; rr < TAPS; ++rr) {
+            const int r = rb + rr;
+            if (r < nin) {
+                const int yi = y0 - RADIUS + r;
+                float v[NP];
+                if (yi >= 0 && yi < h) {
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) v[i] = tin[i * plane + (long)yi * p];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) v[i] = 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+#pragma unroll
+                    for (int k = 0; k < TAPS; ++k) {
+                        const int slot = (rr - k + TAPS) % TAPS;
+                        acc[i][slot] = __builtin_fmaf(tap(taps, i, k), v[i], k == 0 ? 0.f : acc[i][slot]);
+                    }
+                }
+                const int yo = yi - RADIUS;
+                if (r >= 2 * RADIUS) { // yo >= y0, and yo < y1 because r < nin
+                    const int e = (rr + 1) % TAPS;
+                    float b[NP];
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) b[i] = acc[i][e];
+                    const long off = (long)yo * p;
+#pragma unroll
+                    for (int i = 0; i < NP; ++i)
+                        if (blur_out.p[i]) blur_out.p[i][z * blur_stride + off + x] = b[i];
+                    if (dg) {
+#pragma unroll
+                        for (int i = 0; i < NP - 1; ++i) dg[i * plane + off] = b[i] - b[i + 1];
+                    }
+                    if (nb && !(yo & 1)) nb[(long)(yo >> 1) * next_p] = b[S];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Detection.  The reference's acceptance rule depends on where a pixel sits in
+// ITS launch geometry (blocks of 96x32 pixels, three 32-wide tiles per block,
+// tiles of 101x34 floats spaced 3168 floats apart in shared memory).  These
+// constants restate that geometry so the rule can be evaluated per pixel from
+// global memory under any tiling.
+// ---------------------------------------------------------------------------
+constexpr int XT_DATAX = 96;
+constexpr int XT_BDIM = 32;
+constexpr int XT_SDIMX = 101;
+constexpr int XT_WRITTEN = 98;
+constexpr int XT_PLANE_OFF = 3168;
+
+__device__ __forceinline__ float zpad(const float *pl, int w, int p, int h, int x, int y)
+{
+    return (x >= 0 && x < w && y >= 0 && y < h) ? pl[x + (long)p * y] : 0.f;
+}
+
+// value found at (sx,sy) of tile s by a thread of block (bx,by): the head of
+// tile s+1 has overwritten the tail of tile s (cudaSiftD.cu:239-261)
+__device__ float tile_read(const float *d3, long plane, int w, int p, int h, int bx, int by, int s,
+                           int sx, int sy)
+{
+    if (s < 2) {
+        const int lin = sx + XT_SDIMX * sy;
+        if (lin >= XT_PLANE_OFF) {
+            const int j = lin - XT_PLANE_OFF;
+            const int sy2 = j / XT_SDIMX;
+            const int sx2 = j - sy2 * XT_SDIMX;
+            if (sx2 < XT_WRITTEN) {
+                s += 1;
+                sx = sx2;
+                sy = sy2;
+            }
+        }
+    }
+    return zpad(d3 + s * plane, w, p, h, XT_DATAX * bx - 1 + sx, XT_BDIM * by - 1 + sy);
+}
+
+__device__ float center_value(const float *d3, long plane, int w, int p, int h, int x, int y)
+{
+    if ((y & 31) < 30) return d3[plane + x + (long)p * y];
+    return tile_read(d3, plane, w, p, h, x / XT_DATAX, y >> 5, 1, 1 + x % XT_DATAX, 1 + (y & 31));
+}
+
+// 27-cell rank of cudaSiftD.cu:271-284: sum of +1 where centre >= cell, else -1
+__device__ int pixel_rank(const float *d3, long plane, int w, int p, int h, int x, int y)
+{
+    int r = 0;
+    if ((y & 31) < 29) { // no aliased cell in reach: plain neighbourhood, zero outside the image
+        const float pv = d3[plane + x + (long)p * y];
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int m = -1; m < 2; ++m)
+#pragma unroll
+                for (int l = -1; l < 2; ++l)
+                    r += (pv >= zpad(d3 + s * plane, w, p, h, x + l, y + m)) ? 1 : -1;
+        return r;
+    }
+    const int bx = x / XT_DATAX, by = y >> 5;
+    const int sx = 1 + x % XT_DATAX, sy = 1 + (y & 31);
+    const float pv = tile_read(d3, plane, w, p, h, bx, by, 1, sx, sy);
+    for (int s = 0; s < 3; ++s)
+        for (int m = -1; m < 2; ++m)
+            for (int l = -1; l < 2; ++l)
+                r += (pv >= tile_read(d3, plane, w, p, h, bx, by, s, sx + l, sy + m)) ? 1 : -1;
+    return r;
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ dog, long dog_stride,
+                                                     const float *__restrict__ blur,
+                                                     long blur_stride, int w, int p, int h,
+                                                     float edge_limit, float contrast,
+                                                     unsigned *cand, long cand_stride,
+                                                     unsigned *counts, long counts_stride,
+                                                     int group0, int cap)
+{
+    const int lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 64 + lane;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int z = blockIdx.z;
+    const long plane = (long)p * h;
+    dog += z * dog_stride;
+    blur += z * blur_stride;
+    cand += z * cand_stride;
+    counts += z * counts_stride;
+    const int tile = (x % XT_DATAX) / XT_BDIM;
+    // cudaSiftD.cu:289-290; a pixel in the middle tile can never reach rank 9
+    const bool inside = x > 8 && x < w - 8 && y > 8 && y < h - 8 && tile != 1;
+
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        const float *d3 = dog + i * plane;
+        bool hit = false;
+        if (inside) {
+            const float pv = center_value(d3, plane, w, p, h, x, y);
+            if (fabsf(pv) > contrast) {
+                int r = pixel_rank(d3, plane, w, p, h, x, y);
+                if (tile == 2) { // the rank is carried over from the two tiles to the left
+                    r += pixel_rank(d3, plane, w, p, h, x - 64, y);
+                    r += pixel_rank(d3, plane, w, p, h, x - 32, y);
+                }
+                if (r == 9) {
+                    const float *b = blur + i * plane + x + (long)p * y; // blur plane i+1
+                    const float c = b[0];
+                    float Dxx = -2.f * c;
+                    Dxx += b[-1];
+                    Dxx += b[1];
+                    float Dyy = -2.f * c;
+                    Dyy += b[-p];
+                    Dyy += b[p];
+                    float Dxy = c;
+                    Dxy += b[-p - 1];
+                    Dxy -= b[-1];
+                    Dxy -= b[-p];
+                    const float trace = Dxx + Dyy;
+                    const float det = __fadd_rn(__fmul_rn(Dxx, Dyy), __fmul_rn(Dxy, Dxy));
+                    const float lhs = __fdiv_rn(__fmul_rn(trace, trace), det);
+                    hit = lhs < edge_limit;
+                }
+            }
+        }
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd(&counts[group0 + i], (unsigned)__popcll(m));
+            base = __shfl(base, leader);
+            const unsigned idx = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (hit && idx < (unsigned)cap)
+                cand[(long)(group0 + i) * cap + idx] = (unsigned)x | ((unsigned)y << 16);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Gradient sample (gradientKernel cudaSiftD.cu:349-356).  atan2 is evaluated
+// in double with a fixed sequence of IEEE operations and rounded once to
+// float, so the same source gives the same bits on the host.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double atan_small(double t)
+{
+    const double s = t * t;
+    double q = -1.0 / 35.0;
+    q = fma(q, s, 1.0 / 33.0);
+    q = fma(q, s, -1.0 / 31.0);
+    q = fma(q, s, 1.0 / 29.0);
+    q = fma(q, s, -1.0 / 27.0);
+    q = fma(q, s, 1.0 / 25.0);
+    q = fma(q, s, -1.0 / 23.0);
+    q = fma(q, s, 1.0 / 21.0);
+    q = fma(q, s, -1.0 / 19.0);
+    q = fma(q, s, 1.0 / 17.0);
+    q = fma(q, s, -1.0 / 15.0);
+    q = fma(q, s, 1.0 / 13.0);
+    q = fma(q, s, -1.0 / 11.0);
+    q = fma(q, s, 1.0 / 9.0);
+    q = fma(q, s, -1.0 / 7.0);
+    q = fma(q, s, 1.0 / 5.0);
+    q = fma(q, s, -1.0 / 3.0);
+    return fma(t * s, q, t);
+}
+
+__device__ float det_atan2f(float yf, float xf)
+{
+    const double x = (double)xf, y = (double)yf;
+    const double ax = fabs(x), ay = fabs(y);
+    const double mx = ax > ay ? ax : ay;
+    const double mn = ax > ay ? ay : ax;
+    double r;
+    if (mx == 0.0) {
+        r = 0.0;
+    } else {
+        const double a = mn / mx;
+        if (a > 0.41421356237309503) {
+            const double t = (a - 1.0) / (a + 1.0);
+            r = 0.78539816339744831 + atan_small(t);
+        } else {
+            r = atan_small(a);
+        }
+    }
+    if (ay > ax) r = 1.57079632679489662 - r;
+    if (x < 0.0) r = 3.14159265358979323846 - r;
+    if (y < 0.0) r = -r;
+    return (float)r;
+}
+
+__device__ __forceinline__ void grad_at(const float *src, int w, int p, int h, int x, int y,
+                                        float &mag, float &dir)
+{
+    const float up = zpad(src, w, p, h, x, y - 1);
+    const float down = zpad(src, w, p, h, x, y + 1);
+    const float left = zpad(src, w, p, h, x - 1, y);
+    const float right = zpad(src, w, p, h, x + 1, y);
+    const float dx = right - left;
+    const float dy = down - up;
+    mag = sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy))); // correctly rounded (the _rn intrinsic is the fast approximation)
+    dir = (float)((180 / 3.14159265) * (double)det_atan2f(dy, dx)); // PI of utils.h:4
+}
+
+// cudaAssignBin cudaSiftD.h:35-41; theta is within [-360, 360]
+__device__ __forceinline__ int assign_bin(float theta, float bin_range)
+{
+    theta = (theta < 0.f) ? (theta + 360.f) : theta;
+    theta = (theta >= 360.f) ? (theta - 360.f) : theta; // fmodf(theta, 360) on [0, 720)
+    return (int)floorf(__fdiv_rn(theta, bin_range));
+}
+
+struct SiftPointD {
+    float xpos, ypos, scale, orientation;
+    float data[128];
+};
+
+constexpr int REG = 23; // gradient region [x-11, x+11]: covers the rotated 16x16 patch
+
+// One wave per keypoint.  Float sums whose order the reference leaves to
+// atomics are taken in one fixed order: an orientation bin is (sum over
+// samples 0..127 ascending) + (sum over samples 128..255 ascending); a
+// descriptor bin is the sum over its cell's 16 samples, rows then columns.
+__global__ __launch_bounds__(64) void keypoint_kernel(
+    SiftPointD *pts, long pts_stride, unsigned char *meta, const float *arena, long arena_stride,
+    const unsigned *cand, long cand_stride, const unsigned *counts, long counts_stride,
+    const unsigned *base_count, hl_keypoint_args a)
+{
+    __shared__ float s_mag[REG * REG + 3];
+    __shared__ float s_dir[REG * REG + 3];
+    __shared__ float s_w[256];
+    __shared__ int s_b[256];
+
+    const int lane = threadIdx.x;
+    const int z = blockIdx.y;
+    pts += z * pts_stride;
+    if (meta) meta += z * pts_stride * 2;
+    arena += z * arena_stride;
+    cand += z * cand_stride;
+    counts += z * counts_stride;
+    const unsigned base = base_count[z];
+    const unsigned cap = (unsigned)a.cap;
+
+    for (unsigned j = blockIdx.x;; j += gridDim.x) {
+        if (base + j >= cap) break;
+        int g = -1;
+        unsigned start = 0;
+        for (int gg = 0; gg < a.n_groups; ++gg) {
+            const unsigned c = min(counts[gg], cap);
+            if (j < start + c) {
+                g = gg;
+                break;
+            }
+            start += c;
+        }
+        if (g < 0) break;
+        const unsigned local = j - start;
+        const int oi = g / a.n_scales;
+        const int si = g - oi * a.n_scales;
+        const hl_octave oc = a.oct[oi];
+        const unsigned xy = cand[(long)g * cap + local];
+        const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+        const int w = oc.w, h = oc.h, p = oc.p;
+        const float *bl = arena + oc.blur_off + (long)si * p * h; // blur plane si+1
+
+        __syncthreads(); // previous keypoint's readers are done with the LDS arrays
+        for (int e = lane; e < REG * REG; e += 64) {
+            const int ry = e / REG, rx = e - ry * REG;
+            const int px = min(max(x - 11 + rx, 0), w - 1);
+            const int py = min(max(y - 11 + ry, 0), h - 1);
+            float m, d;
+            grad_at(bl, w, p, h, px, py, m, d);
+            s_mag[e] = m;
+            s_dir[e] = d;
+        }
+        __syncthreads();
+
+        // ---- orientation: 16x16 patch [x-7,x+8] x [y-7,y+8], 32 bins ----
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int s = lane + 64 * q;
+            const int tx = s & 15, ty = s >> 4;
+            const int e = (ty + 4) * REG + tx + 4;
+            float wgt = __fmul_rn(s_mag[e], a.wnd[si * 16 + tx]);
+            wgt = __fmul_rn(wgt, a.wnd[si * 16 + ty]);
+            s_w[s] = wgt;
+            s_b[s] = assign_bin(s_dir[e], 11.25f);
+        }
+        __syncthreads();
+        float hsum = 0.f;
+        {
+            const int b = lane & 31;
+            const int s0 = (lane >> 5) * 128;
+            for (int s = s0; s < s0 + 128; ++s)
+                if (s_b[s] == b) hsum = __fadd_rn(hsum, s_w[s]);
+        }
+        hsum = __fadd_rn(hsum, __shfl_down(hsum, 32));
+        float mx = hsum;
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 8));
+        mx = fmaxf(mx, __shfl_xor(mx, 4));
+        mx = fmaxf(mx, __shfl_xor(mx, 2));
+        mx = fmaxf(mx, __shfl_xor(mx, 1));
+        const unsigned long long mm = __ballot(lane < 32 && hsum == mx);
+        const int oidx = mm ? (__ffsll((long long)mm) - 1) : 0; // first maximum wins
+        const float orientation = 11.25f * (float)oidx;
+        __syncthreads();
+
+        // ---- descriptor: rotated 16x16 samples, bilinear, 4x4 cells x 8 bins ----
+        const float cs = a.cos32[oidx], sn = a.sin32[oidx];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int s = lane + 64 * q;
+            const int tx = s & 15, ty = s >> 4;
+            const float dx = (float)tx - 7.5f, dy = (float)ty - 7.5f;
+            const float u = __fadd_rn(__fmul_rn(dx, cs), __fmul_rn(dy, sn));
+            const float v = __fsub_rn(__fmul_rn(dy, cs), __fmul_rn(dx, sn));
+            const float px = __fadd_rn((float)x, u), py = __fadd_rn((float)y, v);
+            const float fx = floorf(px), fy = floorf(py);
+            const float ax = __fsub_rn(px, fx), ay = __fsub_rn(py, fy);
+            // region entry r holds the value of pixel clamp(x-11+r), so the
+            // clamp-to-edge addressing needs no further clamping here
+            const int rx = min(max((int)fx - (x - 11), 0), REG - 2);
+            const int ry = min(max((int)fy - (y - 11), 0), REG - 2);
+            const int e = ry * REG + rx;
+            float val[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float *pl = c ? s_dir : s_mag;
+                const float v00 = pl[e], v10 = pl[e + 1], v01 = pl[e + REG], v11 = pl[e + REG + 1];
+                const float top = __builtin_fmaf(ax, __fsub_rn(v10, v00), v00);
+                const float bot = __builtin_fmaf(ax, __fsub_rn(v11, v01), v01);
+                val[c] = __builtin_fmaf(ay, __fsub_rn(bot, top), top);
+            }
+            float wgt = __fmul_rn(val[0], a.desc_wnd[tx]);
+            wgt = __fmul_rn(wgt, a.desc_wnd[ty]);
+            s_w[s] = wgt;
+            s_b[s] = assign_bin(val[1], 45.f);
+        }
+        __syncthreads();
+        float hv[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = lane + 64 * q;
+            const int cy = e >> 5, cx = (e >> 3) & 3, b = e & 7;
+            float sum = 0.f;
+#pragma unroll
+            for (int ty = 0; ty < 4; ++ty)
+#pragma unroll
+                for (int tx = 0; tx < 4; ++tx) {
+                    const int s = (4 * cy + ty) * 16 + 4 * cx + tx;
+                    if (s_b[s] == b) sum = __fadd_rn(sum, s_w[s]);
+                }
+            hv[q] = sum;
+        }
+        // L1 normalise, clamp at 0.2, L1 normalise (cudaSiftD.cu:186-200); the
+        // 32-lane tree is shflsum (cudaSiftD.h:96-106), the four partial sums
+        // are added in index order
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            float t0 = hv[0], t1 = hv[1];
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) {
+                t0 = __fadd_rn(t0, __shfl_down(t0, off, 32));
+                t1 = __fadd_rn(t1, __shfl_down(t1, off, 32));
+            }
+            float tot = __fadd_rn(__shfl(t0, 0), __shfl(t0, 32));
+            tot = __fadd_rn(tot, __shfl(t1, 0));
+            tot = __fadd_rn(tot, __shfl(t1, 32));
+            hv[0] = __fdiv_rn(hv[0], tot);
+            hv[1] = __fdiv_rn(hv[1], tot);
+            if (pass == 0) {
+                hv[0] = (hv[0] >= 0.2f) ? 0.2f : hv[0];
+                hv[1] = (hv[1] >= 0.2f) ? 0.2f : hv[1];
+            }
+        }
+        SiftPointD *out = pts + (base + j);
+        out->data[lane] = hv[0];
+        out->data[lane + 64] = hv[1];
+        if (lane == 0) {
+            out->xpos = (float)x;
+            out->ypos = (float)y;
+            out->scale = a.scale_value[g];
+            out->orientation = orientation;
+            if (meta) {
+                meta[2 * (base + j)] = (unsigned char)(a.first_octave + oi);
+                meta[2 * (base + j) + 1] = (unsigned char)si;
+            }
+        }
+    }
+}
+
+__global__ void finalize_counts_kernel(unsigned *base_count, const unsigned *counts,
+                                        long counts_stride, int n_groups, int cap, int nimg)
+{
+    const int z = blockIdx.x * blockDim.x + threadIdx.x;
+    if (z >= nimg) return;
+    unsigned long long tot = base_count[z];
+    for (int g = 0; g < n_groups; ++g) tot += min(counts[z * counts_stride + g], (unsigned)cap);
+    base_count[z] = (unsigned)min(tot, (unsigned long long)cap);
+}
+
+// ---- dense stage kernels (one pixel per lane) -------------------------------
+__global__ __launch_bounds__(256) void subtract_kernel(float *dst, const float *a, const float *b,
+                                                       int w, int p, int h)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x < w && y < h) dst[x + (long)p * y] = a[x + (long)p * y] - b[x + (long)p * y];
+}
+
+__global__ __launch_bounds__(256) void copy_kernel(float *dst, const float *src, int w, int p, int h)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x < w && y < h) dst[x + (long)p * y] = src[x + (long)p * y];
+}
+
+__global__ __launch_bounds__(256) void hessian_kernel(float *dst, const float *src, int w, int p,
+                                                      int h)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const long plane = (long)p * h;
+    const float c = src[x + (long)p * y];
+    float Dxx = -2.f * c;
+    Dxx += zpad(src, w, p, h, x - 1, y);
+    Dxx += zpad(src, w, p, h, x + 1, y);
+    float Dyy = -2.f * c;
+    Dyy += zpad(src, w, p, h, x, y - 1);
+    Dyy += zpad(src, w, p, h, x, y + 1);
+    float Dxy = c;
+    Dxy += zpad(src, w, p, h, x - 1, y - 1);
+    Dxy -= zpad(src, w, p, h, x - 1, y);
+    Dxy -= zpad(src, w, p, h, x, y - 1);
+    const long g = x + (long)p * y;
+    dst[g] = Dxx;
+    dst[g + plane] = Dyy;
+    dst[g + 2 * plane] = Dxy;
+}
+
+__global__ __launch_bounds__(256) void gradient_kernel(float *dst, const float *src, int w, int p,
+                                                       int h)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    float m, d;
+    grad_at(src, w, p, h, x, y, m, d);
+    const long g = x + (long)p * y;
+    dst[g] = m;
+    dst[g + (long)p * h] = d;
+}
+
+// ---- timing -----------------------------------------------------------------
+struct TimedLaunch {
+    int kernel;
+    hipEvent_t start, stop;
+};
+std::mutex g_tmu;
+bool g_timing = false;
+std::vector<TimedLaunch> g_pending;
+double g_ms[8];
+long g_launches[8];
+
+struct ScopedTimer {
+    int kernel;
+    hipStream_t s;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool on;
+    ScopedTimer(int k, hipStream_t st) : kernel(k), s(st), on(g_timing)
+    {
+        if (on) {
+            (void)hipEventCreate(&e0);
+            (void)hipEventCreate(&e1);
+            (void)hipEventRecord(e0, s);
+        }
+    }
+    ~ScopedTimer()
+    {
+        if (on) {
+            (void)hipEventRecord(e1, s);
+            std::lock_guard<std::mutex> lk(g_tmu);
+            g_pending.push_back({kernel, e0, e1});
+        }
+    }
+};
+
+void drain_timers()
+{
+    std::lock_guard<std::mutex> lk(g_tmu);
+    for (auto &t : g_pending) {
+        (void)hipEventSynchronize(t.stop);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
+            g_ms[t.kernel] += ms;
+            g_launches[t.kernel] += 1;
+        }
+        (void)hipEventDestroy(t.start);
+        (void)hipEventDestroy(t.stop);
+    }
+    g_pending.clear();
+}
+
+inline int chk(hipError_t e) { return e == hipSuccess ? 0 : -(int)e; }
+inline int launch_status() { return chk(hipGetLastError()); }
+inline int idivup(int a, int b) { return (a + b - 1) / b; }
+
+} // namespace
+
+extern "C" {
+
+int hl_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int hl_set_device(int dev) { return chk(hipSetDevice(dev)); }
+int hl_get_device(void)
+{
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess) return -1;
+    return d;
+}
+int hl_malloc(void **p, size_t bytes) { return chk(hipMalloc(p, bytes)); }
+int hl_malloc_pitch(void **p, size_t *pitch_bytes, size_t width_bytes, size_t height)
+{
+    return chk(hipMallocPitch(p, pitch_bytes, width_bytes, height));
+}
+int hl_free(void *p) { return chk(hipFree(p)); }
+int hl_memset_async(void *p, int v, size_t bytes, void *stream)
+{
+    return chk(hipMemsetAsync(p, v, bytes, (hipStream_t)stream));
+}
+static hipMemcpyKind kind_of(int k)
+{
+    return k == 1 ? hipMemcpyHostToDevice : (k == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice);
+}
+int hl_memcpy_async(void *dst, const void *src, size_t bytes, int kind, void *stream)
+{
+    return chk(hipMemcpyAsync(dst, src, bytes, kind_of(kind), (hipStream_t)stream));
+}
+int hl_memcpy2d_async(void *dst, size_t dpitch, const void *src, size_t spitch, size_t wbytes,
+                      size_t h, int kind, void *stream)
+{
+    return chk(hipMemcpy2DAsync(dst, dpitch, src, spitch, wbytes, h, kind_of(kind), (hipStream_t)stream));
+}
+int hl_stream_create(void **s)
+{
+    hipStream_t st;
+    int r = chk(hipStreamCreate(&st));
+    *s = (void *)st;
+    return r;
+}
+int hl_stream_destroy(void *s) { return chk(hipStreamDestroy((hipStream_t)s)); }
+int hl_stream_sync(void *s) { return chk(hipStreamSynchronize((hipStream_t)s)); }
+int hl_device_sync(void) { return chk(hipDeviceSynchronize()); }
+int hl_host_alloc(void **p, size_t bytes) { return chk(hipHostMalloc(p, bytes, hipHostMallocDefault)); }
+int hl_host_free(void *p) { return chk(hipHostFree(p)); }
+const char *hl_error_string(int code) { return hipGetErrorString((hipError_t)(-code)); }
+
+void hl_timing_enable(int on) { g_timing = on != 0; }
+int hl_timing_read(int kernel, double *ms, long *launches)
+{
+    drain_timers();
+    if (kernel < 0 || kernel >= 8) return -1;
+    *ms = g_ms[kernel];
+    *launches = g_launches[kernel];
+    return 0;
+}
+void hl_timing_reset(void)
+{
+    drain_timers();
+    for (int i = 0; i < 8; ++i) {
+        g_ms[i] = 0;
+        g_launches[i] = 0;
+    }
+}
+
+int hl_row_blur(const float *src, int src_pitch, long src_stride, float *tmp, long tmp_stride,
+                int w, int p, int h, int n_scales, int nimg, const hl_taps *taps, void *stream)
+{
+    if (w <= 0 || h <= 0 || nimg <= 0 || p < w || (p & 3) || src_pitch < w) return -1001;
+    const bool aligned = ((src_pitch & 3) == 0) && ((((size_t)src) & 15) == 0) && ((src_stride & 3) == 0);
+    dim3 grid(idivup(w, 256), idivup(h, 4), nimg), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    ScopedTimer t(0, s);
+#define ROW_LAUNCH(NP)                                                                          \
+    if (aligned)                                                                                \
+        hipLaunchKernelGGL((row_blur_kernel<NP, true>), grid, block, 0, s, src, src_pitch,      \
+                           src_stride, tmp, tmp_stride, w, p, h, *taps);                        \
+    else                                                                                        \
+        hipLaunchKernelGGL((row_blur_kernel<NP, false>), grid, block, 0, s, src, src_pitch,     \
+                           src_stride, tmp, tmp_stride, w, p, h, *taps);
+    if (n_scales == 2) {
+        ROW_LAUNCH(5)
+    } else if (n_scales == 3) {
+        ROW_LAUNCH(6)
+    } else {
+        return -1002;
+    }
+#undef ROW_LAUNCH
+    return launch_status();
+}
+
+int hl_col_blur_dog(const float *tmp, long tmp_stride, const hl_plane_ptrs *blur_out,
+                    long blur_stride, float *dog, long dog_stride, float *next_base,
+                    long next_stride, int next_p, int w, int p, int h, int n_scales, int nimg,
+                    const hl_taps *taps, void *stream)
+{
+    if (w <= 0 || h <= 0 || nimg <= 0 || p < w) return -1001;
+    if (next_base && next_p < (w + 1) / 2) return -1003;
+    // strip height: 19*m - 18 output rows per wave so the unrolled ring is
+    // used in whole turns; fewer, taller strips for large images
+    int m = 6;
+    if ((long)w * h * nimg < (1L << 20)) m = 3;
+    if ((long)w * h * nimg < (1L << 16)) m = 2;
+    const int rows = TAPS * m - 2 * RADIUS;
+    dim3 grid(idivup(w, 256), idivup(h, rows), nimg), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    ScopedTimer t(1, s);
+    if (n_scales == 2)
+        hipLaunchKernelGGL((col_blur_dog_kernel<2>), grid, block, 0, s, tmp, tmp_stride, *blur_out,
+                           blur_stride, dog, dog_stride, next_base, next_stride, next_p, w, p, h,
+                           rows, *taps);
+    else if (n_scales == 3)
+        hipLaunchKernelGGL((col_blur_dog_kernel<3>), grid, block, 0, s, tmp, tmp_stride, *blur_out,
+                           blur_stride, dog, dog_stride, next_base, next_stride, next_p, w, p, h,
+                           rows, *taps);
+    else
+        return -1002;
+    return launch_status();
+}
+
+int hl_detect(const float *dog, long dog_stride, const float *blur, long blur_stride, int w,
+              int p, int h, int n_scales, float r_thresh, float extrema_thresh, unsigned *cand,
+              long cand_stride, unsigned *counts, long counts_stride, int group0, int cap,
+              int nimg, void *stream)
+{
+    if (w <= 0 || h <= 0 || nimg <= 0 || p < w || w > 65535 || h > 65535) return -1001;
+    if (w < 18 || h < 18) return 0; // no pixel satisfies 8 < x < w-8
+    const float edge_limit = (r_thresh * r_thresh) / r_thresh; // cudaSiftD.cu:292
+    dim3 grid(idivup(w, 64), idivup(h, 4), nimg), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    ScopedTimer t(2, s);
+    if (n_scales == 2)
+        hipLaunchKernelGGL((detect_kernel<2>), grid, block, 0, s, dog, dog_stride, blur, blur_stride,
+                           w, p, h, edge_limit, extrema_thresh, cand, cand_stride, counts,
+                           counts_stride, group0, cap);
+    else if (n_scales == 3)
+        hipLaunchKernelGGL((detect_kernel<3>), grid, block, 0, s, dog, dog_stride, blur, blur_stride,
+                           w, p, h, edge_limit, extrema_thresh, cand, cand_stride, counts,
+                           counts_stride, group0, cap);
+    else
+        return -1002;
+    return launch_status();
+}
+
+int hl_keypoints(void *pts, long pts_stride_points, unsigned char *meta, const float *arena,
+                 long arena_stride, const unsigned *cand, long cand_stride, const unsigned *counts,
+                 long counts_stride, const unsigned *base_count, const hl_keypoint_args *args,
+                 int nimg, void *stream)
+{
+    if (nimg <= 0 || args->n_groups <= 0 || args->n_groups > HL_MAX_GROUPS) return -1001;
+    int gx = args->cap < 2048 ? args->cap : 2048;
+    if (gx < 1) gx = 1;
+    dim3 grid(gx, nimg), block(64);
+    hipStream_t s = (hipStream_t)stream;
+    ScopedTimer t(3, s);
+    hipLaunchKernelGGL(keypoint_kernel, grid, block, 0, s, (SiftPointD *)pts, pts_stride_points, meta,
+                       arena, arena_stride, cand, cand_stride, counts, counts_stride, base_count,
+                       *args);
+    return launch_status();
+}
+
+int hl_finalize_counts(unsigned *base_count, const unsigned *counts, long counts_stride,
+                       int n_groups, int cap, int nimg, void *stream)
+{
+    hipLaunchKernelGGL(finalize_counts_kernel, dim3(idivup(nimg, 64)), dim3(64), 0,
+                       (hipStream_t)stream, base_count, counts, counts_stride, n_groups, cap, nimg);
+    return launch_status();
+}
+
+static dim3 px_grid(int w, int h) { return dim3(idivup(w, 64), idivup(h, 4)); }
+
+int hl_subtract(float *dst, const float *a, const float *b, int w, int p, int h, void *stream)
+{
+    hipLaunchKernelGGL(subtract_kernel, px_grid(w, h), dim3(256), 0, (hipStream_t)stream, dst, a, b, w, p, h);
+    return launch_status();
+}
+int hl_hessian(float *dst, const float *src, int w, int p, int h, void *stream)
+{
+    hipLaunchKernelGGL(hessian_kernel, px_grid(w, h), dim3(256), 0, (hipStream_t)stream, dst, src, w, p, h);
+    return launch_status();
+}
+int hl_gradient(float *dst, const float *src, int w, int p, int h, void *stream)
+{
+    hipLaunchKernelGGL(gradient_kernel, px_grid(w, h), dim3(256), 0, (hipStream_t)stream, dst, src, w, p, h);
+    return launch_status();
+}
+int hl_copy(float *dst, const float *src, int w, int p, int h, void *stream)
+{
+    hipLaunchKernelGGL(copy_kernel, px_grid(w, h), dim3(256), 0, (hipStream_t)stream, dst, src, w, p, h);
+    return launch_status();
+}
+
+} // extern "C"
