@@ -1,0 +1,158 @@
+"""CPU suite for the shipped library: the C ABI loads and exports what the header
+declares, and the host-side logic (tables, parameters, loader, writer, sharding)
+is right.  No kernel runs here."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from pnm import read_pnm, write_pnm
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/Sift"
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "sift_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", src)))
+
+
+def test_library_exports_every_declared_symbol(sift):
+    names = declared_functions()
+    assert {"initDeviceConstant", "initDeviceVariables", "extractSift", "getPointCount",
+            "blurOctave", "sift_extract_batch"} <= set(names)
+    raw = ctypes.CDLL(sift.LIB_PATH)
+    missing = [n for n in names if not hasattr(raw, n)]
+    assert not missing, missing
+    assert set(names) == set(sift.SYMBOLS), "the Python binding covers exactly the header"
+
+
+def test_point_record_layout(sift):
+    assert sift.POINT_DTYPE.itemsize == 528  # Sift/src/sift.h:7-13
+    assert sift.POINT_DTYPE.fields["data"][1] == 16
+
+
+def test_missing_library_fails_loudly(sift, monkeypatch):
+    monkeypatch.setattr(sift, "_lib", None)
+    monkeypatch.setattr(sift, "LIB_PATH", "/nonexistent/libsift_amd.so")
+    with pytest.raises(sift.SiftError, match="no CPU fallback"):
+        sift.lib()
+
+
+def test_params_roundtrip_and_validation(sift):
+    d = sift.default_params()
+    assert (d.n_octaves, d.n_scales, d.max_points) == (4, 2, 2500)  # utils.h:7-10
+    assert (d.sigma, d.r_thresh, d.extrema_thresh) == (np.float32(1.6), 10.0, 10.0)
+    sift.set_params(n_octaves=5, n_scales=3, max_points=7)
+    g = sift.get_params()
+    assert (g.n_octaves, g.n_scales, g.max_points) == (5, 3, 7)
+    for bad in (dict(n_scales=5), dict(n_octaves=0), dict(n_octaves=9), dict(max_points=0), dict(sigma=-1.0)):
+        with pytest.raises(sift.SiftError):
+            sift.set_params(**bad)
+    assert sift.get_params().n_scales == 3, "a rejected call changes nothing"
+    sift.set_params()
+
+
+@pytest.mark.parametrize("S", [2, 3])
+def test_library_tables_equal_oracle_tables(sift, oracle_mod, S):
+    sift.set_params(n_scales=S)
+    got = sift.get_tables()
+    want = oracle_mod.tables(oracle_mod.params(n_scales=S))
+    for g, w in zip(got, want):
+        assert np.array_equal(bits(g), bits(w))
+    sift.set_params()
+
+
+def test_text_writer_equals_oracle_writer(sift, oracle_mod):
+    rng = np.random.default_rng(3)
+    pts = np.zeros(5, sift.POINT_DTYPE)
+    pts["xpos"] = rng.integers(9, 900, 5)
+    pts["ypos"] = rng.integers(9, 900, 5)
+    pts["scale"] = [1.6, 2.2627418, 3.2, 4.5254836, 6.4]
+    pts["orientation"] = 11.25 * rng.integers(0, 32, 5)
+    pts["data"] = rng.uniform(0, 0.2, (5, 128))
+    assert sift.format_points(pts) == oracle_mod.format_points(pts.view(oracle_mod.POINT_DTYPE))
+
+
+def test_pnm_loader_matches_gray_rule(sift, oracle_mod, tmp_path):
+    rng = np.random.default_rng(4)
+    rgb = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    write_pnm(tmp_path / "c.ppm", rgb)
+    write_pnm(tmp_path / "g.pgm", rgb[..., 1])
+    assert np.array_equal(sift.load_pnm_gray(tmp_path / "c.ppm"), oracle_mod.gray_q14(rgb).astype(np.float32))
+    assert np.array_equal(sift.load_pnm_gray(tmp_path / "g.pgm"), rgb[..., 1].astype(np.float32))
+    with pytest.raises(sift.SiftError):
+        sift.load_pnm_gray(tmp_path / "absent.ppm")
+    if os.path.isdir(REF):  # the reference's known-answer file
+        res = read_pnm(os.path.join(REF, "result/result.ppm"))[..., 0]
+        assert np.array_equal(sift.load_pnm_gray(os.path.join(REF, "img/img3.ppm")), res.astype(np.float32))
+
+
+def test_synthetic_images_are_integer_valued_and_seeded(sift):
+    a = sift.synth_image(320, 200, seed=5)
+    b = sift.synth_image(320, 200, seed=5, pitch=384)
+    c = sift.synth_image(320, 200, seed=6)
+    assert a.min() >= 0 and a.max() <= 255 and np.array_equal(a, np.round(a))
+    assert np.array_equal(a, b[:, :320]) and not np.array_equal(a, c)
+    assert a.std() > 5
+
+
+def test_shard_indices(sift):
+    from sift_amd.multi_gpu import shard_indices
+
+    for n in (0, 1, 7, 4096):
+        for world in (1, 2, 4, 8):
+            parts = [shard_indices(n, r, world) for r in range(world)]
+            assert sorted(sum(parts, [])) == list(range(n))
+            assert max(map(len, parts)) - min(map(len, parts)) <= 1
+    with pytest.raises(ValueError):
+        shard_indices(4, 2, 2)
+
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+import torch.distributed as dist
+import oracle, sift_amd
+from sift_amd.multi_gpu import extract_sharded, gather_in_image_order
+
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
+pr = oracle.params(n_octaves=2, max_points=4000)
+imgs = np.stack([sift_amd.synth_image(160, 120, seed=40 + i, dense=True) for i in range(5)])
+fn = lambda local, w: oracle.extract_batch(pr, local, w)   # stands in for the GPU extractor
+local = extract_sharded(imgs, 160, fn, dist.get_rank(), 2)
+assert sorted(local) == list(range(dist.get_rank(), 5, 2))
+out = gather_in_image_order(local, 5, dist)
+if dist.get_rank() == 0:
+    ref_pts, ref_counts = oracle.extract_batch(pr, imgs, 160)
+    assert [len(o) for o in out] == ref_counts.tolist() and sum(ref_counts) > 0
+    for i in range(5):
+        assert out[i].tobytes() == ref_pts[i][: ref_counts[i]].tobytes()
+    print("GATHER_OK", ref_counts.tolist())
+else:
+    assert out is None
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_sharding_and_gather_over_gloo(tmp_path):
+    pytest.importorskip("torch")
+    port = 29500 + os.getpid() % 2000
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "GATHER_OK" in outs[0]

@@ -75,3 +75,138 @@ def test_extract_matches_oracle(sift, oracle_mod, w, h, S, O, seed, dense):
     assert len(ref) > 0
     got = _extract_gpu(sift, host, w)
     _assert_points_equal(oracle_mod, got, ref)
+
+
+import os
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_real_image_crop_against_committed_golden(sift, oracle_mod):
+    """A crop of the reference's own Sift/img/img1.ppm (committed as data)."""
+    z = np.load(os.path.join(GOLD, "real_img1_crop.npz"))
+    _params(sift, oracle_mod, n_scales=int(z["n_scales"]), n_octaves=int(z["n_octaves"]), max_points=20000)
+    g = z["gray"].astype(np.float32)
+    got = _extract_gpu(sift, g, g.shape[1])
+    assert oracle_mod.sort_points(got.view(oracle_mod.POINT_DTYPE)).tobytes() == z["points"].tobytes()
+
+
+def test_unaligned_pitch_and_odd_sizes(sift, oracle_mod):
+    pr = _params(sift, oracle_mod, n_scales=2, n_octaves=3, max_points=20000)
+    w, h, pitch = 301, 203, 303  # pitch not a multiple of 4: the scalar staging path
+    host = oracle_mod.pitched(sift.synth_image(w, h, seed=9, dense=True)[:, :w], pitch)
+    ref, _, total = oracle_mod.extract(pr, host, w)
+    assert total == len(ref) > 20
+    _assert_points_equal(oracle_mod, _extract_gpu(sift, host, w), ref)
+
+
+def test_counts_accumulate_until_reset_and_slots_are_independent(sift, oracle_mod):
+    pr = _params(sift, oracle_mod, n_scales=2, n_octaves=2, max_points=5000)
+    a = sift.synth_image(256, 192, seed=21, dense=True)
+    b = sift.synth_image(320, 200, seed=22, dense=True)
+    ra, _, _ = oracle_mod.extract(pr, a, 256)
+    rb, _, _ = oracle_mod.extract(pr, b, 320)
+    da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    p0, p1 = sift.new_point_buffer(), sift.new_point_buffer()
+    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+    sift.initDeviceConstant()
+    sift.initDeviceVariables()
+    sift.extractSift(p0, da, 256, 256, 192, s0, 0, 0)
+    sift.extractSift(p1, db, 320, 320, 200, s1, 1, 0)
+    sift.extractSift(p0, db, 320, 320, 200, s0, 0, 0)  # appends behind the first image's points
+    n0, n1 = sift.getPointCount(0), sift.getPointCount(1)
+    assert n1 == len(rb) and n0 == len(ra) + len(rb)
+    _assert_points_equal(oracle_mod, sift.points_to_numpy(p1, n1), rb)
+    _assert_points_equal(oracle_mod, sift.points_to_numpy(p0, len(ra)), ra)
+    _assert_points_equal(oracle_mod, sift.points_to_numpy(p0, len(rb), offset=len(ra)), rb)
+    sift.initDeviceVariables()
+    assert sift.getPointCount(0) == 0 and sift.getPointCount(1) == 0
+
+
+def test_cap_overflow_keeps_a_subset_and_clamps_the_count(sift, oracle_mod):
+    w, h = 640, 480
+    img = sift.synth_image(w, h, seed=6, dense=True)
+    full, _, _ = oracle_mod.extract(oracle_mod.params(max_points=20000), img, w)
+    assert len(full) >= 300
+    sift.set_params(max_points=256)
+    got = _extract_gpu(sift, img, w)
+    assert len(got) == 256
+    want = {p.tobytes() for p in full}
+    assert all(p.tobytes() in want for p in got), "every kept point is a full-run point, bit for bit"
+    # whole groups in front of the overflowing one are complete (the reference skips later scales)
+    first = full["scale"] == full["scale"][0]
+    if first.sum() < 256:
+        assert (got["scale"] == full["scale"][0]).sum() == first.sum()
+
+
+def test_start_octave_argument(sift, oracle_mod):
+    pr = _params(sift, oracle_mod, n_scales=2, n_octaves=4, max_points=20000)
+    img = sift.synth_image(400, 300, seed=31, dense=True)
+    ref, _, _ = oracle_mod.extract(pr, img, 400, octave0=2)
+    assert len(ref) > 0
+    d = torch.from_numpy(img).cuda()
+    pts = sift.new_point_buffer()
+    sift.initDeviceVariables()
+    sift.extractSift(pts, d, 400, 400, 300, None, 3, 2)
+    n = sift.getPointCount(3)
+    _assert_points_equal(oracle_mod, sift.points_to_numpy(pts, n), ref)
+    sift.extractSift(pts, d, 400, 400, 300, None, 3, 4)  # octaveIdx == n_octaves: nothing to do
+    assert sift.getPointCount(3) == n
+
+
+def test_batch_entry_matches_per_image_oracle(sift, oracle_mod):
+    pr = _params(sift, oracle_mod, n_scales=2, n_octaves=4, max_points=3000)
+    n, w, h = 11, 480, 270
+    imgs = np.stack([sift.synth_image(w, h, seed=100 + i, dense=(i % 2 == 0)) for i in range(n)])
+    ref_pts, ref_counts = oracle_mod.extract_batch(pr, imgs, w, n_threads=8)
+    sift.lib().sift_set_batch_chunk(4)  # 3 launch sets: 4 + 4 + 3
+    d_pts, counts, meta = sift.extract_batch(torch.from_numpy(imgs).cuda(), w, want_meta=True)
+    sift.lib().sift_set_batch_chunk(8)
+    assert counts.tolist() == ref_counts.tolist() and counts.sum() > 100
+    meta = meta.cpu().numpy().reshape(n, pr.max_points, 2)
+    for i in range(n):
+        got = sift.points_to_numpy(d_pts, int(counts[i]), offset=i * pr.max_points)
+        _assert_points_equal(oracle_mod, got, ref_pts[i][: ref_counts[i]])
+        m = meta[i, : counts[i]]
+        sv = np.array([oracle_mod.scale_value(pr, int(s), int(o)) for o, s in m], np.float32)
+        assert np.array_equal(sv, got["scale"]), "meta = (octave, scale index) of each point"
+        assert np.all(np.diff(m[:, 0].astype(int) * 8 + m[:, 1]) >= 0), "grouped by octave then scale"
+
+
+def test_full_size_1080p_batch_properties(sift, oracle_mod):
+    """BASELINE size: 1920x1080, 2 scales, 5 octaves.  One image is checked bit for bit
+    against the oracle; the batch is checked through size-independent properties."""
+    pr = _params(sift, oracle_mod, n_scales=2, n_octaves=5, max_points=2500)
+    w, h, n = 1920, 1080, 6
+    imgs = np.stack([sift.synth_image(w, h, seed=1000 + i, dense=(i == 5)) for i in range(n)])
+    d = torch.from_numpy(imgs).cuda()
+    d_pts, counts = sift.extract_batch(d, w)
+    ref, _, total = oracle_mod.extract(pr, imgs[0], w)
+    assert total == len(ref)
+    _assert_points_equal(oracle_mod, sift.points_to_numpy(d_pts, int(counts[0])), ref)
+    ref5, _, _ = oracle_mod.extract(pr, imgs[5], w)
+    _assert_points_equal(oracle_mod, sift.points_to_numpy(d_pts, int(counts[5]), offset=5 * 2500), ref5)
+    # idempotence: the same batch again gives the same bytes per image once sorted
+    d_pts2, counts2 = sift.extract_batch(d, w)
+    assert counts.tolist() == counts2.tolist()
+    for i in range(n):
+        a = sift.points_to_numpy(d_pts, int(counts[i]), offset=i * 2500)
+        b = sift.points_to_numpy(d_pts2, int(counts[i]), offset=i * 2500)
+        assert oracle_mod.sort_points(a).tobytes() == oracle_mod.sort_points(b).tobytes()
+        assert np.allclose(a["data"].sum(1), 1, atol=1e-5) and np.all(a["orientation"] % 11.25 == 0)
+    # permutation: image order in the batch does not matter
+    d_pts3, counts3 = sift.extract_batch(torch.from_numpy(imgs[::-1].copy()).cuda(), w)
+    assert counts3.tolist() == counts.tolist()[::-1]
+
+
+def test_bad_arguments_are_reported_not_fatal(sift):
+    sift.set_params()
+    pts = sift.new_point_buffer()
+    d = torch.zeros((10, 16), dtype=torch.float32, device="cuda")
+    with pytest.raises(sift.SiftError):
+        sift.extractSift(pts, d, 32, 16, 10, None, 0, 0)  # pitch < width
+    with pytest.raises(sift.SiftError):
+        sift.extractSift(pts, d, 16, 16, 10, None, 99, 0)  # slot out of range
+    sift.initDeviceVariables()
+    sift.extractSift(pts, d, 16, 16, 10, None, 0, 0)  # too small for any keypoint: fine, zero points
+    assert sift.getPointCount(0) == 0

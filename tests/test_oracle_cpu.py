@@ -1,0 +1,253 @@
+"""CPU suite: the oracle against fixtures, closed-form known answers and its own
+second restatement.  No GPU."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from pnm import read_pnm
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+REF = "/root/reference/Sift"
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def read_tables(S):
+    out = {}
+    for line in open(os.path.join(GOLD, f"tables_S{S}.txt")):
+        k, *v = line.split()
+        out[k] = np.array([float.fromhex(t) for t in v], np.float32)
+    return out
+
+
+@pytest.mark.parametrize("S", [2, 3])
+def test_tables_match_hex_fixture(oracle_mod, S):
+    pr = oracle_mod.params(n_scales=S)
+    blur, wnd, desc = oracle_mod.tables(pr)
+    t = read_tables(S)
+    assert np.array_equal(bits(blur.ravel()), bits(t["blur"]))
+    assert np.array_equal(bits(wnd.ravel()), bits(t["wnd"]))
+    assert np.array_equal(bits(desc), bits(t["desc"]))
+    c32, s32 = oracle_mod.rotation_table()
+    assert np.array_equal(bits(c32), bits(t["cos32"])) and np.array_equal(bits(s32), bits(t["sin32"]))
+    sc = [oracle_mod.scale_value(pr, i, o) for o in range(6) for i in range(S)]
+    assert np.array_equal(bits(np.array(sc)), bits(t["scale"]))
+
+
+def test_tables_properties(oracle_mod):
+    pr = oracle_mod.params(n_scales=3)
+    blur, wnd, desc = oracle_mod.tables(pr)
+    assert np.array_equal(bits(blur), bits(blur[:, ::-1])), "taps are exactly symmetric"
+    assert np.allclose(blur.sum(1), 1, atol=1e-6) and np.allclose(wnd.sum(1), 1, atol=1e-6)
+    # sigma_i = 1.6 * sqrt(2)^(i-1): the second plane's centre tap is 1/(sqrt(2 pi) 1.6) renormalised
+    assert abs(blur[1, 9] - 0.2493389) < 1e-6
+    assert abs(oracle_mod.scale_value(pr, 0, 0) - 1.6) < 1e-6
+    assert abs(oracle_mod.scale_value(pr, 2, 1) - 1.6 * 2 ** 2.5) < 1e-4
+
+
+def test_gray_fixture_from_reference_files(oracle_mod):
+    z = np.load(os.path.join(GOLD, "gray_img3_crop.npz"))
+    assert np.array_equal(oracle_mod.gray_q14(z["rgb"]), z["gray"])
+    if os.path.isdir(REF):  # the full known-answer file, where the reference tree is mounted
+        rgb = read_pnm(os.path.join(REF, "img/img3.ppm"))
+        res = read_pnm(os.path.join(REF, "result/result.ppm"))[..., 0]
+        assert hashlib.sha256(res.tobytes()).hexdigest() == str(z["full_gray_sha256"])
+        assert np.array_equal(oracle_mod.gray_q14(rgb), res)
+
+
+def test_constant_image_known_answer(oracle_mod):
+    pr = oracle_mod.params()
+    w, h, p = 150, 90, 256
+    img = oracle_mod.pitched(np.full((h, w), 100, np.float32), p)
+    blur = oracle_mod.yblur(pr, oracle_mod.xblur(pr, img, w), w)
+    inner = blur[:, 9:h - 9, 9:w - 9]
+    assert np.all(np.abs(inner - 100) < 1e-3), "normalised taps reproduce a constant"
+    dog = oracle_mod.dog(pr, blur, w)
+    assert np.all(np.abs(dog[:, 9:h - 9, 9:w - 9]) < 1e-3)
+    assert np.isnan(blur[:, :, w:]).all(), "pad columns are never written"
+    pts, _, total = oracle_mod.extract(pr, img, w)
+    assert total == 0 and len(pts) == 0
+
+
+def test_impulse_known_answer(oracle_mod):
+    pr = oracle_mod.params(n_scales=3)
+    taps, _, _ = oracle_mod.tables(pr)
+    w, h = 64, 48
+    img = np.zeros((h, w), np.float32)
+    img[20, 30] = 1
+    tmp = oracle_mod.xblur(pr, img, w)
+    blur = oracle_mod.yblur(pr, tmp, w)
+    for i in range(pr.n_scales + 3):
+        c = taps[i]
+        # row pass: the impulse at x=30 lands on out[x] with tap k = 30 - x + 9
+        assert np.array_equal(bits(tmp[i, 20, 21:40]), bits(c[::-1]))
+        want = np.outer(c[::-1], c[::-1]).astype(np.float32)  # one rounded product per pixel
+        assert np.array_equal(bits(blur[i, 11:30, 21:40]), bits(want))
+        assert blur[i].sum() == pytest.approx(1, abs=1e-5)
+
+
+def test_zero_padding_border_falloff(oracle_mod):
+    pr = oracle_mod.params()
+    taps, _, _ = oracle_mod.tables(pr)
+    w, h = 40, 30
+    tmp = oracle_mod.xblur(pr, np.ones((h, w), np.float32), w)
+    for i in range(pr.n_scales + 3):
+        for x in (0, 3, 8):
+            s = np.float32(0)
+            for k in range(19):  # chain order, zeros outside the image
+                v = np.float32(1 if 0 <= x - 9 + k < w else 0)
+                s = np.float32(np.float64(taps[i, k]) * np.float64(v) + np.float64(s))
+            assert bits(tmp[i, 5, x]) == bits(s)
+
+
+def test_downsample_and_dog_hessian_gradient_definitions(oracle_mod):
+    rng = np.random.default_rng(0)
+    pr = oracle_mod.params()
+    w, h, p = 37, 23, 64
+    blur = np.full((5, h, p), np.nan, np.float32)
+    blur[:, :, :w] = rng.uniform(0, 255, (5, h, w)).astype(np.float32)
+    dog = oracle_mod.dog(pr, blur, w)
+    assert np.array_equal(bits(dog[:, :, :w]), bits(blur[:4, :, :w] - blur[1:, :, :w]))
+    z = np.zeros((h + 2, w + 2), np.float32)
+    hs = oracle_mod.hessian(pr, blur, w)
+    gr = oracle_mod.gradient(pr, blur, w)
+    for i in range(2):
+        z[1:-1, 1:-1] = blur[i + 1, :, :w]
+        c, l, r, u, d, ul = z[1:-1, 1:-1], z[1:-1, :-2], z[1:-1, 2:], z[:-2, 1:-1], z[2:, 1:-1], z[:-2, :-2]
+        assert np.array_equal(bits(hs[3 * i, :, :w]), bits((-2 * c + l) + r))
+        assert np.array_equal(bits(hs[3 * i + 1, :, :w]), bits((-2 * c + u) + d))
+        assert np.array_equal(bits(hs[3 * i + 2, :, :w]), bits(((c + ul) - l) - u))
+        dx, dy = r - l, d - u
+        assert np.array_equal(bits(gr[2 * i, :, :w]), bits(np.sqrt(dx * dx + dy * dy)))
+        want = np.degrees(np.arctan2(dy.astype(np.float64), dx.astype(np.float64)))
+        assert np.abs(gr[2 * i + 1, :, :w] - want).max() < 1e-4
+    ds = oracle_mod.downsample(blur[2], w)
+    assert ds.shape == (12, 128) and np.array_equal(bits(ds[:, :19]), bits(blur[2, ::2, :w:2]))
+
+
+def test_atan2_accuracy_and_special_cases(oracle_mod):
+    rng = np.random.default_rng(1)
+    ys = np.concatenate([rng.normal(0, 30, 20000), rng.normal(0, 1e-3, 2000), [0, 0, 5, -5, 0, 1e-30]])
+    xs = np.concatenate([rng.normal(0, 30, 20000), rng.normal(0, 1e3, 2000), [3, -3, 0, 0, 0, -1e30]])
+    ys, xs = ys.astype(np.float32), xs.astype(np.float32)
+    got = np.array([oracle_mod.atan2f(y, x) for y, x in zip(ys, xs)], np.float32)
+    exact = np.arctan2(ys.astype(np.float64), xs.astype(np.float64))
+    ulp = np.spacing(np.abs(exact).astype(np.float32)).astype(np.float64)
+    assert (np.abs(got - exact) <= 0.5000001 * ulp + 1e-45).all(), "correctly rounded up to the double error"
+    assert (bits(got) == bits(exact.astype(np.float32))).mean() > 0.9999
+    assert oracle_mod.atan2f(0, 0) == 0 and oracle_mod.atan2f(0, -2) == np.float32(np.pi)
+    assert oracle_mod.atan2f(-3, 0) == np.float32(-np.pi / 2)
+
+
+def test_assign_bin(oracle_mod):
+    ab = oracle_mod.assign_bin
+    assert ab(0, 32) == 0 and ab(11.25, 32) == 1 and ab(11.249, 32) == 0 and ab(359.9, 32) == 31
+    assert ab(-0.001, 32) == 31 and ab(-180, 32) == 16 and ab(180, 32) == 16 and ab(-1e-9, 32) == 0
+    assert ab(90, 8) == 2 and ab(-45, 8) == 7 and ab(44.99, 8) == 0 and ab(360, 8) == 0
+
+
+def _random_planes(rng, w, h, p, amp=25.0):
+    dog = np.full((3, h, p), np.nan, np.float32)
+    dog[:, :, :w] = (rng.normal(0, amp, (3, h, w))).astype(np.float32)
+    # smooth a little so neighbouring ranks correlate as in a real pyramid
+    dog[:, 1:-1, 1:w - 1] = (dog[:, 1:-1, 1:w - 1] + dog[:, :-2, 1:w - 1] + dog[:, 2:, 1:w - 1]
+                             + dog[:, 1:-1, :w - 2] + dog[:, 1:-1, 2:w]) * np.float32(0.4)
+    hess = np.full((3, h, p), np.nan, np.float32)
+    hess[:, :, :w] = rng.normal(0, 5, (3, h, w)).astype(np.float32)
+    return dog, hess
+
+
+@pytest.mark.parametrize("w,h", [(96, 32), (97, 33), (200, 100), (300, 65), (191, 64), (500, 40)])
+def test_extrema_closed_form_equals_literal_block_simulation(oracle_mod, w, h):
+    rng = np.random.default_rng(w * 1000 + h)
+    pr = oracle_mod.params()
+    dog, hess = _random_planes(rng, w, h, (w + 127) // 128 * 128)
+    a = oracle_mod.find_extrema(pr, dog, hess, w, literal=False)
+    b = oracle_mod.find_extrema(pr, dog, hess, w, literal=True)
+    sa = set(map(tuple, a.tolist()))
+    sb = set(map(tuple, b.tolist()))
+    assert len(sa) == len(a) and len(sb) == len(b)
+    assert sa == sb
+    if w >= 200:
+        assert len(sa) > 0
+        xs = np.array(sorted(sa))[:, 0]
+        assert not ((xs % 96 >= 32) & (xs % 96 < 64)).any(), "the middle tile never fires"
+
+
+def test_extrema_on_pipeline_planes_and_aliased_rows(oracle_mod, sift):
+    pr = oracle_mod.params(max_points=100000)
+    w, h = 400, 300
+    img = sift.synth_image(w, h, seed=11, dense=True)
+    blur = oracle_mod.yblur(pr, oracle_mod.xblur(pr, img, w), w)
+    dog, hess = oracle_mod.dog(pr, blur, w), oracle_mod.hessian(pr, blur, w)
+    n_alias = 0
+    for i in range(2):
+        a = oracle_mod.find_extrema(pr, dog[i:i + 3], hess[3 * i:3 * i + 3], w)
+        b = oracle_mod.find_extrema(pr, dog[i:i + 3], hess[3 * i:3 * i + 3], w, literal=True)
+        assert set(map(tuple, a.tolist())) == set(map(tuple, b.tolist())) and len(a) > 20
+        n_alias += int((a[:, 1] % 32 >= 29).sum())
+    assert n_alias > 0, "the case must exercise rows whose shared-memory tiles alias"
+
+
+def test_orientation_and_descriptor_properties(oracle_mod, sift):
+    pr = oracle_mod.params(n_scales=3, n_octaves=4, max_points=20000)
+    img = sift.synth_image(640, 480, seed=1, dense=True)
+    pts, meta, total = oracle_mod.extract(pr, img, 640)
+    assert total == len(pts) > 100
+    assert np.all(pts["orientation"] % 11.25 == 0) and pts["orientation"].min() >= 0 and pts["orientation"].max() < 360
+    assert np.allclose(pts["data"].sum(1), 1, atol=1e-5) and pts["data"].min() >= 0
+    assert np.all(pts["xpos"] == np.round(pts["xpos"])) and pts["xpos"].min() >= 9
+    sv = {(o, i): oracle_mod.scale_value(pr, i, o) for o in range(4) for i in range(3)}
+    assert all(bits(np.float32(p["scale"])) == bits(sv[tuple(m)]) for p, m in zip(pts, meta.tolist()))
+    # points are grouped by octave, then scale, as the reference appends them
+    key = meta[:, 0].astype(int) * 8 + meta[:, 1]
+    assert np.all(np.diff(key) >= 0)
+
+
+def test_extract_matches_committed_golden(oracle_mod, sift):
+    z = np.load(os.path.join(GOLD, "extract_640x480_S3.npz"))
+    pr = oracle_mod.params(n_scales=int(z["n_scales"]), n_octaves=int(z["n_octaves"]), max_points=20000)
+    img = sift.synth_image(640, 480, seed=int(z["seed"]), dense=bool(z["dense"]))
+    if hashlib.sha256(img.tobytes()).hexdigest() != str(z["image_sha256"]):
+        pytest.skip("libm differs from the machine that made the fixture: the synthetic image moved")
+    pts, _, _ = oracle_mod.extract(pr, img, 640)
+    assert oracle_mod.sort_points(pts).tobytes() == z["points"].tobytes()
+
+
+def test_real_image_crop_golden(oracle_mod):
+    z = np.load(os.path.join(GOLD, "real_img1_crop.npz"))
+    pr = oracle_mod.params(n_scales=int(z["n_scales"]), n_octaves=int(z["n_octaves"]), max_points=20000)
+    g = z["gray"].astype(np.float32)
+    pts, _, total = oracle_mod.extract(pr, g, g.shape[1])
+    assert total == len(pts) == len(z["points"])
+    assert oracle_mod.sort_points(pts).tobytes() == z["points"].tobytes()
+
+
+def test_cap_and_octave0_argument(oracle_mod, sift):
+    img = sift.synth_image(640, 480, seed=6, dense=True)
+    full, meta, total = oracle_mod.extract(oracle_mod.params(max_points=20000), img, 640)
+    capped, _, total2 = oracle_mod.extract(oracle_mod.params(max_points=100), img, 640)
+    assert len(capped) == 100 and total2 >= 100
+    assert capped.tobytes() == full[:100].tobytes()
+    # starting at octave 1 treats the image as that octave's base
+    late, meta1, _ = oracle_mod.extract(oracle_mod.params(max_points=20000), img, 640, octave0=1)
+    assert set(meta1[:, 0].tolist()) <= {1, 2, 3}
+    assert (late["scale"] == oracle_mod.scale_value(oracle_mod.params(), 0, 1)).sum() > 0
+
+
+def test_text_format(oracle_mod):
+    pts = np.zeros(2, oracle_mod.POINT_DTYPE)
+    pts["xpos"], pts["ypos"], pts["scale"], pts["orientation"] = [12, 300], [9, 41], [1.6, 2.2627418], [0, 348.75]
+    pts["data"][0, :3] = [0.2, 0.0123456, 1e-7]
+    txt = oracle_mod.format_points(pts)
+    lines = txt.split("\n")
+    assert len(lines) == 3 and lines[2] == ""
+    head = lines[0].split("\t")
+    assert head[:4] == ["12.0", "9.0", "1.600", "0.000"]
+    vals = head[4].split(" ")
+    assert len(vals) == 129 and vals[-1] == "" and vals[:3] == ["0.200000", "0.012346", "0.000000"]
+    assert lines[1].startswith("300.0\t41.0\t2.263\t348.750\t")
