@@ -23,10 +23,6 @@ typedef struct {
     float u[HL_MAX_PLANES][HL_HALF_TAPS];
 } hl_taps;
 
-typedef struct {
-    float *p[HL_MAX_PLANES];
-} hl_plane_ptrs;
-
 /* geometry of one octave inside a per-image arena (offsets in floats) */
 typedef struct {
     int w, h, p;        /* internal pitch p */
@@ -72,10 +68,11 @@ void hl_timing_reset(void);
 /* kernels.  nimg images per launch; image z of a buffer at base + z*stride. */
 int hl_row_blur(const float *src, int src_pitch, long src_stride, float *tmp, long tmp_stride,
                 int w, int p, int h, int n_scales, int nimg, const hl_taps *taps, void *stream);
-/* blur_out: per-plane destination (NULL = not stored); dog: S+2 planes or NULL;
- * next_base: even pixels of plane S with pitch next_p, or NULL */
-int hl_col_blur_dog(const float *tmp, long tmp_stride, const hl_plane_ptrs *blur_out,
-                    long blur_stride, float *dog, long dog_stride, float *next_base,
+/* all_planes != 0: blur receives all S+3 planes and nothing else is stored;
+ * otherwise blur receives planes 1..S (S planes), dog the S+2 DoG planes and
+ * next_base (may be NULL) the even pixels of plane S with pitch next_p */
+int hl_col_blur_dog(const float *tmp, long tmp_stride, float *blur, long blur_stride,
+                    int all_planes, float *dog, long dog_stride, float *next_base,
                     long next_stride, int next_p, int w, int p, int h, int n_scales, int nimg,
                     const hl_taps *taps, void *stream);
 /* appends (x | y<<16) of accepted pixels of scales 0..S-1 to

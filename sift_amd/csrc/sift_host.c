@@ -304,7 +304,6 @@ static int enqueue_extract(slot_ctx *c, SiftPoint *pts, unsigned char *meta, con
     for (int o = oct0; o < O; ++o) {
         const int oi = o - oct0;
         const int ww = c->ow[oi], hh = c->oh[oi], pp = c->op[oi];
-        const long plane = (long)pp * hh;
         if (o == oct0)
             r = hl_row_blur(imgs, pitch, img_stride, A + c->tmp_off, AS, ww, pp, hh, S, nimg,
                             &g_taps, stream);
@@ -312,14 +311,10 @@ static int enqueue_extract(slot_ctx *c, SiftPoint *pts, unsigned char *meta, con
             r = hl_row_blur(A + c->base_off[oi], pp, AS, A + c->tmp_off, AS, ww, pp, hh, S, nimg,
                             &g_taps, stream);
         if (r) return fail_hl(r, "row blur");
-        hl_plane_ptrs bo;
-        memset(&bo, 0, sizeof bo);
-        for (int i = 1; i <= S; ++i)
-            bo.p[i] = A + c->blur_off[oi] + (long)(i - 1) * plane;
         float *next = (o + 1 < O) ? A + c->base_off[oi + 1] : NULL;
         const int next_p = (o + 1 < O) ? c->op[oi + 1] : 0;
-        r = hl_col_blur_dog(A + c->tmp_off, AS, &bo, AS, A + c->dog_off, AS, next, AS, next_p, ww,
-                            pp, hh, S, nimg, &g_taps, stream);
+        r = hl_col_blur_dog(A + c->tmp_off, AS, A + c->blur_off[oi], AS, 0, A + c->dog_off, AS, next,
+                            AS, next_p, ww, pp, hh, S, nimg, &g_taps, stream);
         if (r) return fail_hl(r, "column blur");
         r = hl_detect(A + c->dog_off, AS, A + c->blur_off[oi], AS, ww, pp, hh, S, g_params.r_thresh,
                       g_params.extrema_thresh, c->cand, c->cand_stride, c->counts, HL_MAX_GROUPS,
@@ -546,12 +541,8 @@ void blurOctave(float *dst, float *src, int width, int pitch, int height, void *
     }
     r = hl_row_blur(src, pitch, 0, (float *)tmp, 0, width, pitch, height, S, 1, &g_taps, stream);
     if (r) fail_hl(r, "blurOctave row pass");
-    hl_plane_ptrs bo;
-    memset(&bo, 0, sizeof bo);
-    for (int i = 0; i < S + 3; ++i)
-        bo.p[i] = dst + i * plane;
     if (!r) {
-        r = hl_col_blur_dog((const float *)tmp, 0, &bo, 0, NULL, 0, NULL, 0, 0, width, pitch,
+        r = hl_col_blur_dog((const float *)tmp, 0, dst, 0, 1, NULL, 0, NULL, 0, 0, width, pitch,
                             height, S, 1, &g_taps, stream);
         if (r) fail_hl(r, "blurOctave column pass");
     }

@@ -102,17 +102,25 @@ __global__ __launch_bounds__(256) void row_blur_kernel(const float *__restrict__
 // strip of rows.  Each input row r is loaded once and scattered into the 19
 // partial sums it belongs to: out[yo] accumulates fmaf(c[k], in[yo-9+k], .)
 // with k ascending as the input row ascends, which is exactly the reference's
-// chain order.  The 19 live sums per plane sit in a register ring whose slot
-// index is static because the row loop is unrolled by 19.
+// chain order.  The live sums of a plane sit in a register ring of 20 slots
+// (19 in use, one being recycled); the row loop is unrolled by 20 so every
+// slot index is static.  Input rows are fetched COL_PF rows ahead of their use
+// to keep enough bytes in flight per wave.
+// STAGE = true: store all S+3 blur planes and nothing else (blurOctave entry);
+// STAGE = false: store blur planes 1..S, the S+2 DoG planes and the even
+// pixels of plane S as the next octave's base.
 // ---------------------------------------------------------------------------
-template <int S>
-__global__ __launch_bounds__(256) void col_blur_dog_kernel(
-    const float *__restrict__ tmp, long tmp_stride, hl_plane_ptrs blur_out, long blur_stride,
+constexpr int COL_RING = 20;
+constexpr int COL_PF = 4;
+
+template <int S, bool STAGE>
+__global__ __launch_bounds__(64) void col_blur_dog_kernel(
+    const float *__restrict__ tmp, long tmp_stride, float *__restrict__ blur, long blur_stride,
     float *__restrict__ dog, long dog_stride, float *__restrict__ next_base, long next_stride,
     int next_p, int w, int p, int h, int rows, hl_taps taps)
 {
     constexpr int NP = S + 3;
-    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int x = blockIdx.x * 64 + threadIdx.x;
     if (x >= w) return;
     const int y0 = blockIdx.y * rows;
     const int y1 = min(y0 + rows, h);
@@ -120,52 +128,65 @@ __global__ __launch_bounds__(256) void col_blur_dog_kernel(
     const long plane = (long)p * h;
     const int z = blockIdx.z;
     const float *tin = tmp + z * tmp_stride + x;
-    float *dg = dog ? dog + z * dog_stride + x : nullptr;
-    float *nb = (next_base && !(x & 1)) ? next_base + z * next_stride + (x >> 1) : nullptr;
+    float *bl = blur + z * blur_stride + x;
+    float *dg = STAGE ? nullptr : dog + z * dog_stride + x;
+    float *nb = (!STAGE && next_base && !(x & 1)) ? next_base + z * next_stride + (x >> 1) : nullptr;
 
-    float acc[NP][TAPS];
+    float acc[NP][COL_RING];
 #pragma unroll
     for (int i = 0; i < NP; ++i)
 #pragma unroll
-        for (int k = 0; k < TAPS; ++k) acc[i][k] = 0.f;
+        for (int k = 0; k < COL_RING; ++k) acc[i][k] = 0.f;
 
-    for (int rb = 0; rb < nin; rb += TAPS) {
+    float pre[COL_PF][NP];
 #pragma unroll
-        for (int rr = 0; rr < TAPS; ++rr) {
+    for (int q = 0; q < COL_PF; ++q) {
+        const int yi = y0 - RADIUS + q;
+        const bool ok = yi >= 0 && yi < h; // q < nin always: nin >= 19
+#pragma unroll
+        for (int i = 0; i < NP; ++i) pre[q][i] = ok ? tin[i * plane + (long)yi * p] : 0.f;
+    }
+
+    for (int rb = 0; rb < nin; rb += COL_RING) {
+#pragma unroll
+        for (int rr = 0; rr < COL_RING; ++rr) {
             const int r = rb + rr;
+            float v[NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) v[i] = pre[rr % COL_PF][i];
+            {
+                const int rn = r + COL_PF;
+                const int yn = y0 - RADIUS + rn;
+                const bool ok = rn < nin && yn >= 0 && yn < h;
+#pragma unroll
+                for (int i = 0; i < NP; ++i) pre[rr % COL_PF][i] = ok ? tin[i * plane + (long)yn * p] : 0.f;
+            }
             if (r < nin) {
-                const int yi = y0 - RADIUS + r;
-                float v[NP];
-                if (yi >= 0 && yi < h) {
-#pragma unroll
-                    for (int i = 0; i < NP; ++i) v[i] = tin[i * plane + (long)yi * p];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < NP; ++i) v[i] = 0.f;
-                }
 #pragma unroll
                 for (int i = 0; i < NP; ++i) {
 #pragma unroll
                     for (int k = 0; k < TAPS; ++k) {
-                        const int slot = (rr - k + TAPS) % TAPS;
+                        const int slot = (rr - k + COL_RING) % COL_RING;
                         acc[i][slot] = __builtin_fmaf(tap(taps, i, k), v[i], k == 0 ? 0.f : acc[i][slot]);
                     }
                 }
-                const int yo = yi - RADIUS;
-                if (r >= 2 * RADIUS) { // yo >= y0, and yo < y1 because r < nin
-                    const int e = (rr + 1) % TAPS;
+                if (r >= 2 * RADIUS) { // output row yo = y0 + r - 18 is complete; yo < y1 because r < nin
+                    const int yo = y0 + r - 2 * RADIUS;
+                    const int e = (rr - 2 * RADIUS + COL_RING) % COL_RING;
                     float b[NP];
 #pragma unroll
                     for (int i = 0; i < NP; ++i) b[i] = acc[i][e];
                     const long off = (long)yo * p;
+                    if (STAGE) {
 #pragma unroll
-                    for (int i = 0; i < NP; ++i)
-                        if (blur_out.p[i]) blur_out.p[i][z * blur_stride + off + x] = b[i];
-                    if (dg) {
+                        for (int i = 0; i < NP; ++i) bl[i * plane + off] = b[i];
+                    } else {
+#pragma unroll
+                        for (int i = 1; i <= S; ++i) bl[(i - 1) * plane + off] = b[i];
 #pragma unroll
                         for (int i = 0; i < NP - 1; ++i) dg[i * plane + off] = b[i] - b[i + 1];
+                        if (nb && !(yo & 1)) nb[(long)(yo >> 1) * next_p] = b[S];
                     }
-                    if (nb && !(yo & 1)) nb[(long)(yo >> 1) * next_p] = b[S];
                 }
             }
         }
@@ -191,29 +212,27 @@ __device__ __forceinline__ float zpad(const float *pl, int w, int p, int h, int 
 }
 
 // value found at (sx,sy) of tile s by a thread of block (bx,by): the head of
-// tile s+1 has overwritten the tail of tile s (cudaSiftD.cu:239-261)
-__device__ float tile_read(const float *d3, long plane, int w, int p, int h, int bx, int by, int s,
-                           int sx, int sy)
+// tile s+1 has overwritten the tail of tile s (cudaSiftD.cu:239-261).
+// Branch-free, so independent reads issue back to back.
+__device__ __forceinline__ float tile_read(const float *d3, long plane, int w, int p, int h, int bx,
+                                           int by, int s, int sx, int sy)
 {
-    if (s < 2) {
-        const int lin = sx + XT_SDIMX * sy;
-        if (lin >= XT_PLANE_OFF) {
-            const int j = lin - XT_PLANE_OFF;
-            const int sy2 = j / XT_SDIMX;
-            const int sx2 = j - sy2 * XT_SDIMX;
-            if (sx2 < XT_WRITTEN) {
-                s += 1;
-                sx = sx2;
-                sy = sy2;
-            }
-        }
-    }
-    return zpad(d3 + s * plane, w, p, h, XT_DATAX * bx - 1 + sx, XT_BDIM * by - 1 + sy);
+    const int lin = sx + XT_SDIMX * sy;
+    const int j = lin - XT_PLANE_OFF;
+    const int sy2 = j / XT_SDIMX;
+    const int sx2 = j - sy2 * XT_SDIMX;
+    const bool moved = s < 2 && j >= 0 && sx2 < XT_WRITTEN;
+    s = moved ? s + 1 : s;
+    sx = moved ? sx2 : sx;
+    sy = moved ? sy2 : sy;
+    const int x = XT_DATAX * bx - 1 + sx, y = XT_BDIM * by - 1 + sy;
+    const bool in = x >= 0 && x < w && y >= 0 && y < h;
+    const float v = d3[s * plane + (in ? x + (long)p * y : 0)];
+    return in ? v : 0.f;
 }
 
-__device__ float center_value(const float *d3, long plane, int w, int p, int h, int x, int y)
+__device__ __forceinline__ float center_value(const float *d3, long plane, int w, int p, int h, int x, int y)
 {
-    if ((y & 31) < 30) return d3[plane + x + (long)p * y];
     return tile_read(d3, plane, w, p, h, x / XT_DATAX, y >> 5, 1, 1 + x % XT_DATAX, 1 + (y & 31));
 }
 
@@ -221,27 +240,41 @@ __device__ float center_value(const float *d3, long plane, int w, int p, int h, 
 __device__ int pixel_rank(const float *d3, long plane, int w, int p, int h, int x, int y)
 {
     int r = 0;
-    if ((y & 31) < 29) { // no aliased cell in reach: plain neighbourhood, zero outside the image
-        const float pv = d3[plane + x + (long)p * y];
+    if ((y & 31) < 29 && x > 0 && x < w - 1 && y > 0 && y < h - 1) {
+        // no aliased cell in reach and no image border: the plain neighbourhood
+        const float *c = d3 + x + (long)p * y;
+        const float pv = c[plane];
 #pragma unroll
         for (int s = 0; s < 3; ++s)
 #pragma unroll
             for (int m = -1; m < 2; ++m)
 #pragma unroll
-                for (int l = -1; l < 2; ++l)
-                    r += (pv >= zpad(d3 + s * plane, w, p, h, x + l, y + m)) ? 1 : -1;
+                for (int l = -1; l < 2; ++l) r += (pv >= c[s * plane + m * p + l]) ? 1 : -1;
         return r;
     }
     const int bx = x / XT_DATAX, by = y >> 5;
     const int sx = 1 + x % XT_DATAX, sy = 1 + (y & 31);
     const float pv = tile_read(d3, plane, w, p, h, bx, by, 1, sx, sy);
+#pragma unroll
     for (int s = 0; s < 3; ++s)
+#pragma unroll
         for (int m = -1; m < 2; ++m)
+#pragma unroll
             for (int l = -1; l < 2; ++l)
                 r += (pv >= tile_read(d3, plane, w, p, h, bx, by, s, sx + l, sy + m)) ? 1 : -1;
     return r;
 }
 
+constexpr int DET_ROWS = 8; // image rows per wave
+
+// One wave per 256-pixel wide, DET_ROWS tall block of pixels, four pixels per
+// lane and row (one 16-byte load per centre plane and row, all issued before
+// the first use).  The contrast test |DoG| > threshold runs first because it
+// rejects almost every pixel from data already in registers.  Survivors go
+// through a per-wave LDS queue so that a cluster of them (they come in
+// clusters) is spread over all 64 lanes before the 27- or 81-cell rank and
+// the edge test are evaluated.  Accepted pixels are appended with one atomic
+// per wave (ballot + prefix count).
 template <int S>
 __global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ dog, long dog_stride,
                                                      const float *__restrict__ blur,
@@ -251,28 +284,67 @@ __global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ d
                                                      unsigned *counts, long counts_stride,
                                                      int group0, int cap)
 {
+    __shared__ unsigned q_xy[4][DET_ROWS * 256];
+    __shared__ unsigned q_n[4];
     const int lane = threadIdx.x & 63;
-    const int x = blockIdx.x * 64 + lane;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int wv = threadIdx.x >> 6;
+    const int x4 = blockIdx.x * 256 + 4 * lane;
+    const int y0 = (blockIdx.y * 4 + wv) * DET_ROWS;
     const int z = blockIdx.z;
     const long plane = (long)p * h;
     dog += z * dog_stride;
     blur += z * blur_stride;
     cand += z * cand_stride;
     counts += z * counts_stride;
-    const int tile = (x % XT_DATAX) / XT_BDIM;
-    // cudaSiftD.cu:289-290; a pixel in the middle tile can never reach rank 9
-    const bool inside = x > 8 && x < w - 8 && y > 8 && y < h - 8 && tile != 1;
+    // 96 and 32 are multiples of 4, so the four pixels of a lane share a tile;
+    // a pixel in the middle tile can never reach rank 9
+    const int tile = (x4 % XT_DATAX) / XT_BDIM;
+    const bool lane_ok = x4 < w && tile != 1;
 
 #pragma unroll
     for (int i = 0; i < S; ++i) {
         const float *d3 = dog + i * plane;
-        bool hit = false;
-        if (inside) {
-            const float pv = center_value(d3, plane, w, p, h, x, y);
-            if (fabsf(pv) > contrast) {
+        if (lane == 0) q_n[wv] = 0;
+        float v[DET_ROWS][4];
+#pragma unroll
+        for (int r = 0; r < DET_ROWS; ++r) {
+            const int y = y0 + r;
+            const bool ok = lane_ok && y > 8 && y < h - 8; // cudaSiftD.cu:289-290
+            if ((y & 31) < 30) { // wave-uniform
+                const float4 t = *reinterpret_cast<const float4 *>(d3 + plane + (ok ? x4 + (long)p * y : 0));
+                v[r][0] = t.x;
+                v[r][1] = t.y;
+                v[r][2] = t.z;
+                v[r][3] = t.w;
+            } else { // the centre value itself is read through an aliased cell
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    v[r][q] = center_value(d3, plane, w, p, h, ok ? min(x4 + q, w - 1) : 0, ok ? y : 0);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < DET_ROWS; ++r) {
+            const int y = y0 + r;
+            const bool ok = lane_ok && y > 8 && y < h - 8;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (ok && x4 + q > 8 && x4 + q < w - 8 && fabsf(v[r][q]) > contrast) {
+                    const unsigned slot = atomicAdd(&q_n[wv], 1u);
+                    q_xy[wv][slot] = (unsigned)(x4 + q) | ((unsigned)y << 16);
+                }
+        }
+        __syncthreads();
+        const unsigned nq = q_n[wv];
+        for (unsigned e0 = 0; e0 < nq; e0 += 64) { // wave-uniform trip count
+            const unsigned e = e0 + lane;
+            bool hit = false;
+            unsigned xy = 0;
+            if (e < nq) {
+                xy = q_xy[wv][e];
+                const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
                 int r = pixel_rank(d3, plane, w, p, h, x, y);
-                if (tile == 2) { // the rank is carried over from the two tiles to the left
+                if ((x % XT_DATAX) >= 2 * XT_BDIM) { // the rank is carried over from the two tiles to the left
                     r += pixel_rank(d3, plane, w, p, h, x - 64, y);
                     r += pixel_rank(d3, plane, w, p, h, x - 32, y);
                 }
@@ -290,22 +362,21 @@ __global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ d
                     Dxy -= b[-1];
                     Dxy -= b[-p];
                     const float trace = Dxx + Dyy;
-                    const float det = __fadd_rn(__fmul_rn(Dxx, Dyy), __fmul_rn(Dxy, Dxy));
-                    const float lhs = __fdiv_rn(__fmul_rn(trace, trace), det);
-                    hit = lhs < edge_limit;
+                    const float det = Dxx * Dyy + Dxy * Dxy; // PLUS, and no contraction (cudaSiftD.cu:288)
+                    hit = (trace * trace) / det < edge_limit;
                 }
             }
+            const unsigned long long m = __ballot(hit);
+            if (m) {
+                const int leader = __ffsll((long long)m) - 1;
+                unsigned base = 0;
+                if (lane == leader) base = atomicAdd(&counts[group0 + i], (unsigned)__popcll(m));
+                base = __shfl(base, leader);
+                const unsigned idx = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (hit && idx < (unsigned)cap) cand[(long)(group0 + i) * cap + idx] = xy;
+            }
         }
-        const unsigned long long m = __ballot(hit);
-        if (m) {
-            const int leader = __ffsll((long long)m) - 1;
-            unsigned base = 0;
-            if (lane == leader) base = atomicAdd(&counts[group0 + i], (unsigned)__popcll(m));
-            base = __shfl(base, leader);
-            const unsigned idx = base + __popcll(m & ((1ull << lane) - 1ull));
-            if (hit && idx < (unsigned)cap)
-                cand[(long)(group0 + i) * cap + idx] = (unsigned)x | ((unsigned)y << 16);
-        }
+        __syncthreads();
     }
 }
 
@@ -777,32 +848,37 @@ int hl_row_blur(const float *src, int src_pitch, long src_stride, float *tmp, lo
     return launch_status();
 }
 
-int hl_col_blur_dog(const float *tmp, long tmp_stride, const hl_plane_ptrs *blur_out,
-                    long blur_stride, float *dog, long dog_stride, float *next_base,
-                    long next_stride, int next_p, int w, int p, int h, int n_scales, int nimg,
-                    const hl_taps *taps, void *stream)
+int hl_col_blur_dog(const float *tmp, long tmp_stride, float *blur, long blur_stride, int all_planes,
+                    float *dog, long dog_stride, float *next_base, long next_stride, int next_p,
+                    int w, int p, int h, int n_scales, int nimg, const hl_taps *taps, void *stream)
 {
-    if (w <= 0 || h <= 0 || nimg <= 0 || p < w) return -1001;
+    if (w <= 0 || h <= 0 || nimg <= 0 || p < w || !tmp || !blur) return -1001;
+    if (!all_planes && !dog) return -1001;
     if (next_base && next_p < (w + 1) / 2) return -1003;
-    // strip height: 19*m - 18 output rows per wave so the unrolled ring is
-    // used in whole turns; fewer, taller strips for large images
+    // One wave per block.  Strip height 20*m - 18 output rows, so the unrolled
+    // ring is used in whole turns: tall strips re-read fewer apron rows, short
+    // strips give small octaves enough waves to cover the chip.
     int m = 6;
-    if ((long)w * h * nimg < (1L << 20)) m = 3;
-    if ((long)w * h * nimg < (1L << 16)) m = 2;
-    const int rows = TAPS * m - 2 * RADIUS;
-    dim3 grid(idivup(w, 256), idivup(h, rows), nimg), block(256);
+    while (m > 2 && (long)idivup(w, 64) * idivup(h, COL_RING * m - 2 * RADIUS) * nimg < 2048) --m;
+    const int rows = COL_RING * m - 2 * RADIUS;
+    dim3 grid(idivup(w, 64), idivup(h, rows), nimg), block(64);
     hipStream_t s = (hipStream_t)stream;
     ScopedTimer t(1, s);
-    if (n_scales == 2)
-        hipLaunchKernelGGL((col_blur_dog_kernel<2>), grid, block, 0, s, tmp, tmp_stride, *blur_out,
-                           blur_stride, dog, dog_stride, next_base, next_stride, next_p, w, p, h,
-                           rows, *taps);
+#define COL_LAUNCH(SS, ST)                                                                         \
+    hipLaunchKernelGGL((col_blur_dog_kernel<SS, ST>), grid, block, 0, s, tmp, tmp_stride, blur,    \
+                       blur_stride, dog, dog_stride, next_base, next_stride, next_p, w, p, h,     \
+                       rows, *taps)
+    if (n_scales == 2 && all_planes)
+        COL_LAUNCH(2, true);
+    else if (n_scales == 2)
+        COL_LAUNCH(2, false);
+    else if (n_scales == 3 && all_planes)
+        COL_LAUNCH(3, true);
     else if (n_scales == 3)
-        hipLaunchKernelGGL((col_blur_dog_kernel<3>), grid, block, 0, s, tmp, tmp_stride, *blur_out,
-                           blur_stride, dog, dog_stride, next_base, next_stride, next_p, w, p, h,
-                           rows, *taps);
+        COL_LAUNCH(3, false);
     else
         return -1002;
+#undef COL_LAUNCH
     return launch_status();
 }
 
@@ -811,10 +887,11 @@ int hl_detect(const float *dog, long dog_stride, const float *blur, long blur_st
               long cand_stride, unsigned *counts, long counts_stride, int group0, int cap,
               int nimg, void *stream)
 {
-    if (w <= 0 || h <= 0 || nimg <= 0 || p < w || w > 65535 || h > 65535) return -1001;
+    if (w <= 0 || h <= 0 || nimg <= 0 || p < w || (p & 3) || w > 65535 || h > 65535) return -1001;
+    if ((((size_t)dog) & 15) || (dog_stride & 3)) return -1004;
     if (w < 18 || h < 18) return 0; // no pixel satisfies 8 < x < w-8
     const float edge_limit = (r_thresh * r_thresh) / r_thresh; // cudaSiftD.cu:292
-    dim3 grid(idivup(w, 64), idivup(h, 4), nimg), block(256);
+    dim3 grid(idivup(w, 256), idivup(h, 4 * DET_ROWS), nimg), block(256);
     hipStream_t s = (hipStream_t)stream;
     ScopedTimer t(2, s);
     if (n_scales == 2)

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Aggregates rocprofv3 --pmc CSV output per kernel: mean counter value per
+dispatch, plus the gfx950 corrections for HBM traffic (FETCH_SIZE counts 128-byte
+requests as 64 bytes for wide coalesced reads, so the read side is doubled;
+FETCH_SIZE and WRITE_SIZE are in KiB)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    for k in ("row_blur", "col_blur_dog", "detect", "keypoint", "finalize", "fillBuffer", "copyBuffer",
+              "subtract", "hessian", "gradient"):
+        if k in name:
+            return k
+    return name[:40]
+
+
+def main(root):
+    acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = short(row["Kernel_Name"])
+            a = acc[k][row["Counter_Name"]]
+            a[0] += float(row["Counter_Value"])
+            a[1] += 1
+    dur = {}
+    for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            dur[short(row["Name"])] = (float(row["AverageNs"]), int(row["Calls"]))
+    for k in sorted(acc):
+        print(f"== {k}")
+        c = {n: v[0] / max(v[1], 1) for n, v in acc[k].items()}
+        for n in sorted(c):
+            print(f"   {n:24s} {c[n]:16.1f}  (mean of {acc[k][n][1]} dispatches)")
+        if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
+            rd = c.get("FETCH_SIZE", 0) * 1024 * 2
+            wr = c.get("WRITE_SIZE", 0) * 1024
+            print(f"   HBM-side bytes per launch: read {rd/1e6:.2f} MB (FETCH_SIZE x2), write {wr/1e6:.2f} MB")
+            if k in dur:
+                ns = dur[k][0]
+                print(f"   avg duration {ns/1e3:.1f} us over {dur[k][1]} calls -> {(rd+wr)/ns:.1f} GB/s counted traffic")
+        if "TCC_HIT_sum" in c:
+            t = c["TCC_HIT_sum"] + c.get("TCC_MISS_sum", 0)
+            if t:
+                print(f"   L2 hit rate {c['TCC_HIT_sum']/t:.3f}")
+        if "SQ_LDS_IDX_ACTIVE" in c and c["SQ_LDS_IDX_ACTIVE"]:
+            print(f"   LDS bank-conflict cycles / LDS active cycles = {c.get('SQ_LDS_BANK_CONFLICT',0)/c['SQ_LDS_IDX_ACTIVE']:.4f}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
