@@ -100,6 +100,10 @@ int sift_extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
                        int width, int pitch, int height, void *stream);
 /* images worked on per launch set (default 8); arenas grow to match */
 void sift_set_batch_chunk(int images_per_launch);
+/* launch sets in flight at once, each on a private stream and arena: 1 or 2
+ * (default 2: the short kernels of the small octaves of one set overlap the
+ * long kernels of the other) */
+void sift_set_batch_lanes(int n);
 
 /* ---- thin device layer (replaces CudaImage / SiftData helpers,
  * cudaImage.cu:23-68, sift.cu:30-61, and the stream calls in sift.cu:94-130) */
@@ -141,7 +145,8 @@ enum {
     SIFT_K_COL_BLUR_DOG = 1,
     SIFT_K_DETECT = 2,
     SIFT_K_KEYPOINT = 3,
-    SIFT_K_COUNT = 4
+    SIFT_K_PYRAMID = 4, /* fused row + column pass of the hot path */
+    SIFT_K_COUNT = 5
 };
 /* When enabled, every launch of the pyramid kernels is bracketed by events on
  * its own stream; sift_timing_read drains them (synchronises). */

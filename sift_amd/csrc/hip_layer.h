@@ -56,6 +56,10 @@ int hl_stream_create(void **s);
 int hl_stream_destroy(void *s);
 int hl_stream_sync(void *s);
 int hl_device_sync(void);
+int hl_event_create(void **e);
+int hl_event_destroy(void *e);
+int hl_event_record(void *e, void *stream);
+int hl_stream_wait_event(void *stream, void *e);
 int hl_host_alloc(void **p, size_t bytes);
 int hl_host_free(void *p);
 const char *hl_error_string(int code);
@@ -75,6 +79,11 @@ int hl_col_blur_dog(const float *tmp, long tmp_stride, float *blur, long blur_st
                     int all_planes, float *dog, long dog_stride, float *next_base,
                     long next_stride, int next_p, int w, int p, int h, int n_scales, int nimg,
                     const hl_taps *taps, void *stream);
+/* fused row pass + column pass: src image(s) -> blur planes 1..S, S+2 DoG
+ * planes and (optionally) the next octave's base; no intermediate in HBM */
+int hl_pyramid(const float *src, int src_pitch, long src_stride, float *blur, long blur_stride,
+               float *dog, long dog_stride, float *next_base, long next_stride, int next_p, int w,
+               int p, int h, int n_scales, int nimg, const hl_taps *taps, void *stream);
 /* appends (x | y<<16) of accepted pixels of scales 0..S-1 to
  * cand + (group0+i)*cap, counting in counts[group0+i] */
 int hl_detect(const float *dog, long dog_stride, const float *blur, long blur_stride, int w,

@@ -18,7 +18,8 @@
 
 #define REF_PI 3.14159265 /* utils.h:4 */
 #define MAX_DEV 16
-#define BATCH_SLOT SIFT_MAX_SLOTS
+#define BATCH_SLOT SIFT_MAX_SLOTS /* two batch arenas follow the stream slots */
+#define N_LANES 2
 
 /* ---- state ---------------------------------------------------------------- */
 typedef struct {
@@ -34,8 +35,6 @@ typedef struct {
     unsigned *counts; /* nimg * HL_MAX_GROUPS */
     unsigned *cand;   /* nimg * groups * cap */
     long cand_stride;
-    unsigned *base_count; /* batch slot only: one word per image of the batch */
-    int base_count_n;
     void *last_stream;
 } slot_ctx;
 
@@ -47,7 +46,14 @@ static float g_wnd[4 * 16];
 static float g_desc[16];
 static float g_cos32[32], g_sin32[32];
 static hl_taps g_taps;
-static slot_ctx g_slots[MAX_DEV][SIFT_MAX_SLOTS + 1];
+static slot_ctx g_slots[MAX_DEV][SIFT_MAX_SLOTS + N_LANES];
+/* the batch entry alternates launch sets between two private streams so the
+ * short, latency-bound kernels of one set run beside the long ones of the other */
+static void *g_lane_stream[MAX_DEV][N_LANES];
+static void *g_lane_event[MAX_DEV][N_LANES + 1];
+static unsigned *g_batch_count[MAX_DEV];
+static int g_batch_count_n[MAX_DEV];
+static int g_lanes = N_LANES;
 static unsigned *g_slot_counter[MAX_DEV]; /* device, SIFT_MAX_SLOTS words */
 static int g_chunk = 8;
 static char g_err[512] = "";
@@ -188,7 +194,6 @@ static void free_slot(slot_ctx *c)
     if (c->arena) hl_free(c->arena);
     if (c->counts) hl_free(c->counts);
     if (c->cand) hl_free(c->cand);
-    if (c->base_count) hl_free(c->base_count);
     memset(c, 0, sizeof *c);
 }
 
@@ -198,8 +203,23 @@ void sift_shutdown(void)
     int dev = hl_get_device();
     if (dev >= 0 && dev < MAX_DEV) {
         hl_device_sync();
-        for (int s = 0; s <= SIFT_MAX_SLOTS; ++s)
+        for (int s = 0; s < SIFT_MAX_SLOTS + N_LANES; ++s)
             free_slot(&g_slots[dev][s]);
+        for (int l = 0; l < N_LANES; ++l)
+            if (g_lane_stream[dev][l]) {
+                hl_stream_destroy(g_lane_stream[dev][l]);
+                g_lane_stream[dev][l] = NULL;
+            }
+        for (int l = 0; l <= N_LANES; ++l)
+            if (g_lane_event[dev][l]) {
+                hl_event_destroy(g_lane_event[dev][l]);
+                g_lane_event[dev][l] = NULL;
+            }
+        if (g_batch_count[dev]) {
+            hl_free(g_batch_count[dev]);
+            g_batch_count[dev] = NULL;
+            g_batch_count_n[dev] = 0;
+        }
         if (g_slot_counter[dev]) {
             hl_free(g_slot_counter[dev]);
             g_slot_counter[dev] = NULL;
@@ -236,12 +256,7 @@ static int ensure_arena(slot_ctx *c, int w, int h, int oct0, int nimg)
         int r = hl_stream_sync(c->last_stream);
         if (r) return fail_hl(r, "draining slot");
     }
-    unsigned *keep_base = c->base_count;
-    int keep_n = c->base_count_n;
-    c->base_count = NULL;
     free_slot(c);
-    c->base_count = keep_base;
-    c->base_count_n = keep_n;
 
     long off = 0;
     int ww = w, hh = h;
@@ -293,8 +308,8 @@ static int ensure_arena(slot_ctx *c, int w, int h, int oct0, int nimg)
  * a dozen blocking copies per octave; here the octaves are a loop over a
  * preplanned arena and nothing blocks. */
 static int enqueue_extract(slot_ctx *c, SiftPoint *pts, unsigned char *meta, const float *imgs,
-                           long img_stride, int nimg, int w, int pitch, int h, int oct0,
-                           unsigned *base_count, void *stream)
+                           long img_stride, int nimg, int pitch, int oct0, unsigned *base_count,
+                           void *stream)
 {
     const int S = g_params.n_scales, O = g_params.n_octaves, cap = g_params.max_points;
     int r = hl_memset_async(c->counts, 0, sizeof(unsigned) * HL_MAX_GROUPS * nimg, stream);
@@ -304,18 +319,15 @@ static int enqueue_extract(slot_ctx *c, SiftPoint *pts, unsigned char *meta, con
     for (int o = oct0; o < O; ++o) {
         const int oi = o - oct0;
         const int ww = c->ow[oi], hh = c->oh[oi], pp = c->op[oi];
-        if (o == oct0)
-            r = hl_row_blur(imgs, pitch, img_stride, A + c->tmp_off, AS, ww, pp, hh, S, nimg,
-                            &g_taps, stream);
-        else
-            r = hl_row_blur(A + c->base_off[oi], pp, AS, A + c->tmp_off, AS, ww, pp, hh, S, nimg,
-                            &g_taps, stream);
-        if (r) return fail_hl(r, "row blur");
         float *next = (o + 1 < O) ? A + c->base_off[oi + 1] : NULL;
         const int next_p = (o + 1 < O) ? c->op[oi + 1] : 0;
-        r = hl_col_blur_dog(A + c->tmp_off, AS, A + c->blur_off[oi], AS, 0, A + c->dog_off, AS, next,
-                            AS, next_p, ww, pp, hh, S, nimg, &g_taps, stream);
-        if (r) return fail_hl(r, "column blur");
+        if (o == oct0)
+            r = hl_pyramid(imgs, pitch, img_stride, A + c->blur_off[oi], AS, A + c->dog_off, AS,
+                           next, AS, next_p, ww, pp, hh, S, nimg, &g_taps, stream);
+        else
+            r = hl_pyramid(A + c->base_off[oi], pp, AS, A + c->blur_off[oi], AS, A + c->dog_off, AS,
+                           next, AS, next_p, ww, pp, hh, S, nimg, &g_taps, stream);
+        if (r) return fail_hl(r, "pyramid pass");
         r = hl_detect(A + c->dog_off, AS, A + c->blur_off[oi], AS, ww, pp, hh, S, g_params.r_thresh,
                       g_params.extrema_thresh, c->cand, c->cand_stride, c->counts, HL_MAX_GROUPS,
                       oi * S, cap, nimg, stream);
@@ -404,7 +416,7 @@ void extractSift(SiftPoint *siftPt, float *d_src, int width, int pitch, int heig
         slot_ctx *c = &g_slots[dev][streamIdx];
         if (ensure_arena(c, width, height, octaveIdx, 1))
             break;
-        enqueue_extract(c, siftPt, NULL, d_src, 0, 1, width, pitch, height, octaveIdx,
+        enqueue_extract(c, siftPt, NULL, d_src, 0, 1, pitch, octaveIdx,
                         g_slot_counter[dev] + streamIdx, stream);
     } while (0);
     pthread_mutex_unlock(&g_mu);
@@ -443,6 +455,27 @@ int getPointCount(int streamIdx)
 }
 
 /* ---- batch ------------------------------------------------------------------ */
+static int ensure_lanes(int dev)
+{
+    for (int l = 0; l < N_LANES; ++l)
+        if (!g_lane_stream[dev][l]) {
+            int r = hl_stream_create(&g_lane_stream[dev][l]);
+            if (r) return fail_hl(r, "creating batch streams");
+        }
+    for (int l = 0; l <= N_LANES; ++l)
+        if (!g_lane_event[dev][l]) {
+            int r = hl_event_create(&g_lane_event[dev][l]);
+            if (r) return fail_hl(r, "creating batch events");
+        }
+    return 0;
+}
+
+void sift_set_batch_lanes(int n)
+{
+    if (n >= 1 && n <= N_LANES)
+        g_lanes = n;
+}
+
 int sift_extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts, const float *d_imgs,
                        long img_stride, int n, int width, int pitch, int height, void *stream)
 {
@@ -465,15 +498,22 @@ int sift_extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts, c
             set_err("sift_extract_batch: no usable HIP device");
             break;
         }
-        slot_ctx *c = &g_slots[dev][BATCH_SLOT];
         const int chunk = n < g_chunk ? n : g_chunk;
-        if (ensure_arena(c, width, height, 0, chunk))
+        const int n_sets = (n + chunk - 1) / chunk;
+        const int lanes = n_sets < g_lanes ? n_sets : g_lanes;
+        if (ensure_lanes(dev))
             break;
-        if (c->base_count_n < n) {
-            if (c->base_count) {
-                hl_stream_sync(c->last_stream);
-                hl_free(c->base_count);
-                c->base_count = NULL;
+        int bad = 0;
+        for (int l = 0; l < lanes && !bad; ++l)
+            bad = ensure_arena(&g_slots[dev][BATCH_SLOT + l], width, height, 0, chunk);
+        if (bad)
+            break;
+        if (g_batch_count_n[dev] < n) {
+            if (g_batch_count[dev]) {
+                hl_device_sync();
+                hl_free(g_batch_count[dev]);
+                g_batch_count[dev] = NULL;
+                g_batch_count_n[dev] = 0;
             }
             void *p = NULL;
             int r = hl_malloc(&p, sizeof(unsigned) * (size_t)n);
@@ -481,28 +521,41 @@ int sift_extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts, c
                 fail_hl(r, "allocating batch counters");
                 break;
             }
-            c->base_count = (unsigned *)p;
-            c->base_count_n = n;
+            g_batch_count[dev] = (unsigned *)p;
+            g_batch_count_n[dev] = n;
         }
-        int r = hl_memset_async(c->base_count, 0, sizeof(unsigned) * (size_t)n, stream);
+        unsigned *bc = g_batch_count[dev];
+        int r = hl_memset_async(bc, 0, sizeof(unsigned) * (size_t)n, stream);
+        /* fork: the private streams start after everything queued on the caller's stream */
+        if (!r) r = hl_event_record(g_lane_event[dev][N_LANES], stream);
+        for (int l = 0; l < lanes && !r; ++l)
+            r = hl_stream_wait_event(g_lane_stream[dev][l], g_lane_event[dev][N_LANES]);
         if (r) {
-            fail_hl(r, "zeroing batch counters");
+            fail_hl(r, "starting batch streams");
             break;
         }
         const int cap = g_params.max_points;
-        int bad = 0;
-        for (int i0 = 0; i0 < n && !bad; i0 += chunk) {
+        for (int k = 0; k < n_sets && !bad; ++k) {
+            const int i0 = k * chunk;
             const int m = (n - i0) < chunk ? (n - i0) : chunk;
-            bad = enqueue_extract(c, d_pts + (long)i0 * cap, d_meta ? d_meta + 2L * i0 * cap : NULL,
-                                  d_imgs + (long)i0 * img_stride, img_stride, m, width, pitch,
-                                  height, 0, c->base_count + i0, stream);
+            const int l = k % lanes;
+            bad = enqueue_extract(&g_slots[dev][BATCH_SLOT + l], d_pts + (long)i0 * cap,
+                                  d_meta ? d_meta + 2L * i0 * cap : NULL,
+                                  d_imgs + (long)i0 * img_stride, img_stride, m, pitch, 0, bc + i0,
+                                  g_lane_stream[dev][l]);
+        }
+        /* join: the caller's stream continues after both private streams */
+        for (int l = 0; l < lanes; ++l) {
+            int r2 = hl_event_record(g_lane_event[dev][l], g_lane_stream[dev][l]);
+            if (!r2) r2 = hl_stream_wait_event(stream, g_lane_event[dev][l]);
+            if (r2 && !r) r = r2;
         }
         if (bad)
             break;
-        r = hl_memcpy_async(h_counts, c->base_count, sizeof(unsigned) * (size_t)n, 2, stream);
+        if (!r) r = hl_memcpy_async(h_counts, bc, sizeof(unsigned) * (size_t)n, 2, stream);
         if (!r) r = hl_stream_sync(stream);
         if (r) {
-            fail_hl(r, "reading batch counters");
+            fail_hl(r, "finishing batch");
             break;
         }
         rc = 0;

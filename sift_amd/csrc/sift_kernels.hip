@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 
 #include <mutex>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "hip_layer.h"
@@ -21,6 +23,20 @@ namespace {
 
 constexpr int TAPS = HL_TAPS;
 constexpr int RADIUS = 9;
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>).
+// Used where a register ring must be indexed statically (a "#pragma unroll"
+// that the optimiser declines turns the ring into scratch memory).
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 __device__ __forceinline__ float tap(const hl_taps &t, int plane, int k)
 {
@@ -148,8 +164,8 @@ __global__ __launch_bounds__(64) void col_blur_dog_kernel(
     }
 
     for (int rb = 0; rb < nin; rb += COL_RING) {
-#pragma unroll
-        for (int rr = 0; rr < COL_RING; ++rr) {
+        static_for<COL_RING>([&](auto rr_c) {
+            constexpr int rr = decltype(rr_c)::value;
             const int r = rb + rr;
             float v[NP];
 #pragma unroll
@@ -189,7 +205,133 @@ __global__ __launch_bounds__(64) void col_blur_dog_kernel(
                     }
                 }
             }
+        });
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Fused pyramid pass: row blur, column blur, DoG and down-sampling in one
+// kernel, so the S+3 row-blurred planes never travel to HBM and back.
+// One wave per block owns 64 columns and walks down a strip of rows.  Per
+// input row it stages the 88 source pixels [x0-12, x0+76) in LDS (zero outside
+// the image), every lane reads its own 19-pixel window and forms the S+3
+// row-blurred values of its column (xblurMultiKernel's chain), which are then
+// scattered into the column ring exactly as col_blur_dog_kernel does
+// (yblurKernel's chain).  Source rows are fetched FZ_PF rows ahead into
+// registers; the LDS row buffer has two slots so the write of row r+1 is
+// issued a whole step before its first read.
+// ---------------------------------------------------------------------------
+constexpr int FZ_PF = 4;
+constexpr int FZ_STAGE = 88; // floats staged per row
+constexpr int FZ_LOADERS = FZ_STAGE / 4;
+
+template <int S, bool ALIGNED>
+__global__ __launch_bounds__(64) void pyramid_kernel(
+    const float *__restrict__ src, int src_pitch, long src_stride, float *__restrict__ blur,
+    long blur_stride, float *__restrict__ dog, long dog_stride, float *__restrict__ next_base,
+    long next_stride, int next_p, int w, int p, int h, int rows, hl_taps taps)
+{
+    constexpr int NP = S + 3;
+    __shared__ float lds[2][96];
+    const int lane = threadIdx.x;
+    const int x0 = blockIdx.x * 64;
+    const int x = x0 + lane;
+    const bool col_ok = x < w;
+    const int y0 = blockIdx.y * rows;
+    const int y1 = min(y0 + rows, h);
+    const int nin = (y1 - y0) + 2 * RADIUS;
+    const long plane = (long)p * h;
+    const int z = blockIdx.z;
+    src += z * src_stride;
+    float *bl = blur + z * blur_stride + x;
+    float *dg = dog + z * dog_stride + x;
+    float *nb = (next_base && !(x & 1)) ? next_base + z * next_stride + (x >> 1) : nullptr;
+
+    // source fetch of one row: ALIGNED: lanes 0..21 one float4 each;
+    // otherwise every lane one float and lanes 0..23 a second one
+    const int xs = ALIGNED ? x0 - 12 + 4 * lane : x0 - 12 + lane;
+    auto fetch = [&](int r) -> float4 {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int yi = y0 - RADIUS + r;
+        if (r < nin && yi >= 0 && yi < h) { // wave-uniform
+            const float *row = src + (long)yi * src_pitch;
+            if (ALIGNED) {
+                if (lane < FZ_LOADERS && xs >= 0 && xs < w) {
+                    v = *reinterpret_cast<const float4 *>(row + xs);
+                    if (xs + 1 >= w) v.y = 0.f;
+                    if (xs + 2 >= w) v.z = 0.f;
+                    if (xs + 3 >= w) v.w = 0.f;
+                }
+            } else {
+                if (xs >= 0 && xs < w) v.x = row[xs];
+                if (lane < FZ_STAGE - 64 && xs + 64 >= 0 && xs + 64 < w) v.y = row[xs + 64];
+            }
         }
+        return v;
+    };
+    auto stage = [&](int slot, const float4 &v) {
+        if (ALIGNED) {
+            if (lane < FZ_LOADERS) *reinterpret_cast<float4 *>(&lds[slot][4 * lane]) = v;
+        } else {
+            lds[slot][lane] = v.x;
+            if (lane < FZ_STAGE - 64) lds[slot][lane + 64] = v.y;
+        }
+    };
+
+    float acc[NP][COL_RING];
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+#pragma unroll
+        for (int k = 0; k < COL_RING; ++k) acc[i][k] = 0.f;
+
+    float4 g[FZ_PF];
+#pragma unroll
+    for (int q = 0; q < FZ_PF; ++q) g[q] = fetch(q);
+    stage(0, g[0]);
+    g[0] = fetch(FZ_PF);
+
+    for (int rb = 0; rb < nin; rb += COL_RING) {
+        static_for<COL_RING>([&](auto rr_c) {
+            constexpr int rr = decltype(rr_c)::value;
+            const int r = rb + rr;
+            // row r+1 goes to the other slot; its register is refilled with row r+1+FZ_PF
+            stage((rr + 1) & 1, g[(rr + 1) % FZ_PF]);
+            g[(rr + 1) % FZ_PF] = fetch(r + 1 + FZ_PF);
+            if (r < nin) {
+                float win[TAPS];
+#pragma unroll
+                for (int k = 0; k < TAPS; ++k) win[k] = lds[rr & 1][lane + 3 + k];
+                float v[NP];
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int k = 0; k < TAPS; ++k) sum = __builtin_fmaf(tap(taps, i, k), win[k], sum);
+                    v[i] = sum;
+                }
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+#pragma unroll
+                    for (int k = 0; k < TAPS; ++k) {
+                        const int slot = (rr - k + COL_RING) % COL_RING;
+                        acc[i][slot] = __builtin_fmaf(tap(taps, i, k), v[i], k == 0 ? 0.f : acc[i][slot]);
+                    }
+                }
+                if (r >= 2 * RADIUS && col_ok) { // output row yo = y0 + r - 18 is complete
+                    const int yo = y0 + r - 2 * RADIUS;
+                    const int e = (rr - 2 * RADIUS + COL_RING) % COL_RING;
+                    float b[NP];
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) b[i] = acc[i][e];
+                    const long off = (long)yo * p;
+#pragma unroll
+                    for (int i = 1; i <= S; ++i) bl[(i - 1) * plane + off] = b[i];
+#pragma unroll
+                    for (int i = 0; i < NP - 1; ++i) dg[i * plane + off] = b[i] - b[i + 1];
+                    if (nb && !(yo & 1)) nb[(long)(yo >> 1) * next_p] = b[S];
+                }
+            }
+        });
     }
 }
 
@@ -800,6 +942,19 @@ int hl_stream_create(void **s)
 int hl_stream_destroy(void *s) { return chk(hipStreamDestroy((hipStream_t)s)); }
 int hl_stream_sync(void *s) { return chk(hipStreamSynchronize((hipStream_t)s)); }
 int hl_device_sync(void) { return chk(hipDeviceSynchronize()); }
+int hl_event_create(void **e)
+{
+    hipEvent_t ev;
+    int r = chk(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    *e = (void *)ev;
+    return r;
+}
+int hl_event_destroy(void *e) { return chk(hipEventDestroy((hipEvent_t)e)); }
+int hl_event_record(void *e, void *stream) { return chk(hipEventRecord((hipEvent_t)e, (hipStream_t)stream)); }
+int hl_stream_wait_event(void *stream, void *e)
+{
+    return chk(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)e, 0));
+}
 int hl_host_alloc(void **p, size_t bytes) { return chk(hipHostMalloc(p, bytes, hipHostMallocDefault)); }
 int hl_host_free(void *p) { return chk(hipHostFree(p)); }
 const char *hl_error_string(int code) { return hipGetErrorString((hipError_t)(-code)); }
@@ -879,6 +1034,37 @@ int hl_col_blur_dog(const float *tmp, long tmp_stride, float *blur, long blur_st
     else
         return -1002;
 #undef COL_LAUNCH
+    return launch_status();
+}
+
+int hl_pyramid(const float *src, int src_pitch, long src_stride, float *blur, long blur_stride,
+               float *dog, long dog_stride, float *next_base, long next_stride, int next_p, int w,
+               int p, int h, int n_scales, int nimg, const hl_taps *taps, void *stream)
+{
+    if (w <= 0 || h <= 0 || nimg <= 0 || p < w || src_pitch < w || !src || !blur || !dog) return -1001;
+    if (next_base && next_p < (w + 1) / 2) return -1003;
+    const bool aligned = ((src_pitch & 3) == 0) && ((((size_t)src) & 15) == 0) && ((src_stride & 3) == 0);
+    int m = 6; // strip height 20*m - 18, as in hl_col_blur_dog
+    while (m > 2 && (long)idivup(w, 64) * idivup(h, COL_RING * m - 2 * RADIUS) * nimg < 2048) --m;
+    const int rows = COL_RING * m - 2 * RADIUS;
+    dim3 grid(idivup(w, 64), idivup(h, rows), nimg), block(64);
+    hipStream_t s = (hipStream_t)stream;
+    ScopedTimer t(4, s);
+#define PYR_LAUNCH(SS, AL)                                                                        \
+    hipLaunchKernelGGL((pyramid_kernel<SS, AL>), grid, block, 0, s, src, src_pitch, src_stride,   \
+                       blur, blur_stride, dog, dog_stride, next_base, next_stride, next_p, w, p,  \
+                       h, rows, *taps)
+    if (n_scales == 2 && aligned)
+        PYR_LAUNCH(2, true);
+    else if (n_scales == 2)
+        PYR_LAUNCH(2, false);
+    else if (n_scales == 3 && aligned)
+        PYR_LAUNCH(3, true);
+    else if (n_scales == 3)
+        PYR_LAUNCH(3, false);
+    else
+        return -1002;
+#undef PYR_LAUNCH
     return launch_status();
 }
 
