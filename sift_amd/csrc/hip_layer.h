@@ -79,11 +79,14 @@ int hl_col_blur_dog(const float *tmp, long tmp_stride, float *blur, long blur_st
                     int all_planes, float *dog, long dog_stride, float *next_base,
                     long next_stride, int next_p, int w, int p, int h, int n_scales, int nimg,
                     const hl_taps *taps, void *stream);
-/* fused row pass + column pass: src image(s) -> blur planes 1..S, S+2 DoG
- * planes and (optionally) the next octave's base; no intermediate in HBM */
-int hl_pyramid(const float *src, int src_pitch, long src_stride, float *blur, long blur_stride,
-               float *dog, long dog_stride, float *next_base, long next_stride, int next_p, int w,
-               int p, int h, int n_scales, int nimg, const hl_taps *taps, void *stream);
+/* fused row pass + column pass: source -> blur planes 1..S and S+2 DoG planes,
+ * no intermediate in HBM.  subsample != 0: the source is the previous octave's
+ * blur plane S (src_w x src_h) and is read at its even rows and columns, so
+ * w = ceil(src_w/2), h = ceil(src_h/2).  p must be a multiple of 64: columns
+ * [w, p) of the destination planes are written with don't-care values. */
+int hl_pyramid(const float *src, int src_w, int src_h, int src_pitch, long src_stride, int subsample,
+               float *blur, long blur_stride, float *dog, long dog_stride, int w, int p, int h,
+               int n_scales, int nimg, const hl_taps *taps, void *stream);
 /* appends (x | y<<16) of accepted pixels of scales 0..S-1 to
  * cand + (group0+i)*cap, counting in counts[group0+i] */
 int hl_detect(const float *dog, long dog_stride, const float *blur, long blur_stride, int w,

@@ -28,8 +28,7 @@ typedef struct {
     int w, h, S, O, oct0, cap, nimg;
     float *arena;
     long arena_stride; /* floats per image */
-    long tmp_off, dog_off;
-    long base_off[SIFT_MAX_OCTAVES];
+    long dog_off;
     int ow[SIFT_MAX_OCTAVES], oh[SIFT_MAX_OCTAVES], op[SIFT_MAX_OCTAVES];
     long blur_off[SIFT_MAX_OCTAVES];
     unsigned *counts; /* nimg * HL_MAX_GROUPS */
@@ -242,10 +241,9 @@ static int ensure_slot_counter(int dev)
     return 0;
 }
 
-/* Plans (or re-plans) the per-image arena: first-octave sized row-pass and DoG
- * scratch shared by all octaves, S kept blur planes per octave (planes 1..S:
- * the Hessian, the gradients and the next octave read nothing else), and the
- * down-sampled base of every later octave. */
+/* Plans (or re-plans) the per-image arena: first-octave sized DoG scratch shared
+ * by all octaves and S kept blur planes per octave (planes 1..S: the Hessian,
+ * the gradients and the next octave read nothing else). */
 static int ensure_arena(slot_ctx *c, int w, int h, int oct0, int nimg)
 {
     const int S = g_params.n_scales, O = g_params.n_octaves, cap = g_params.max_points;
@@ -261,8 +259,6 @@ static int ensure_arena(slot_ctx *c, int w, int h, int oct0, int nimg)
     long off = 0;
     int ww = w, hh = h;
     const int p0 = ialignup(w, 64);
-    c->tmp_off = off;
-    off += lalign((long)p0 * h * (S + 3), 64);
     c->dog_off = off;
     off += lalign((long)p0 * h * (S + 2), 64);
     for (int o = oct0; o < O; ++o) {
@@ -272,10 +268,6 @@ static int ensure_arena(slot_ctx *c, int w, int h, int oct0, int nimg)
         c->op[oi] = (o == oct0) ? p0 : ialignup(ww, 128); /* cudaSiftH.cu:46 */
         c->blur_off[oi] = off;
         off += lalign((long)c->op[oi] * hh * S, 64);
-        if (o > oct0) {
-            c->base_off[oi] = off;
-            off += lalign((long)c->op[oi] * hh, 64);
-        }
         ww = idivup(ww, 2); /* cudaSiftH.cu:44-45 */
         hh = idivup(hh, 2);
     }
@@ -319,14 +311,13 @@ static int enqueue_extract(slot_ctx *c, SiftPoint *pts, unsigned char *meta, con
     for (int o = oct0; o < O; ++o) {
         const int oi = o - oct0;
         const int ww = c->ow[oi], hh = c->oh[oi], pp = c->op[oi];
-        float *next = (o + 1 < O) ? A + c->base_off[oi + 1] : NULL;
-        const int next_p = (o + 1 < O) ? c->op[oi + 1] : 0;
         if (o == oct0)
-            r = hl_pyramid(imgs, pitch, img_stride, A + c->blur_off[oi], AS, A + c->dog_off, AS,
-                           next, AS, next_p, ww, pp, hh, S, nimg, &g_taps, stream);
-        else
-            r = hl_pyramid(A + c->base_off[oi], pp, AS, A + c->blur_off[oi], AS, A + c->dog_off, AS,
-                           next, AS, next_p, ww, pp, hh, S, nimg, &g_taps, stream);
+            r = hl_pyramid(imgs, ww, hh, pitch, img_stride, 0, A + c->blur_off[oi], AS,
+                           A + c->dog_off, AS, ww, pp, hh, S, nimg, &g_taps, stream);
+        else /* cudaSiftH.cu:50-52: the next octave is the even pixels of blur plane S */
+            r = hl_pyramid(A + c->blur_off[oi - 1] + (long)(S - 1) * c->op[oi - 1] * c->oh[oi - 1],
+                           c->ow[oi - 1], c->oh[oi - 1], c->op[oi - 1], AS, 1, A + c->blur_off[oi],
+                           AS, A + c->dog_off, AS, ww, pp, hh, S, nimg, &g_taps, stream);
         if (r) return fail_hl(r, "pyramid pass");
         r = hl_detect(A + c->dog_off, AS, A + c->blur_off[oi], AS, ww, pp, hh, S, g_params.r_thresh,
                       g_params.extrema_thresh, c->cand, c->cand_stride, c->counts, HL_MAX_GROUPS,

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64) void col_blur_dog_kernel(
     }
 
     for (int rb = 0; rb < nin; rb += COL_RING) {
-        static_for<COL_RING>([&](auto rr_c) {
+        static_for<COL_RING>([&](auto rr_c) __attribute__((always_inline)) {
             constexpr int rr = decltype(rr_c)::value;
             const int r = rb + rr;
             float v[NP];
@@ -210,71 +210,118 @@ __global__ __launch_bounds__(64) void col_blur_dog_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// Fused pyramid pass: row blur, column blur, DoG and down-sampling in one
-// kernel, so the S+3 row-blurred planes never travel to HBM and back.
+// Fused pyramid pass: row blur, column blur and DoG in one kernel, so the S+3
+// row-blurred planes never travel to HBM and back.
 // One wave per block owns 64 columns and walks down a strip of rows.  Per
 // input row it stages the 88 source pixels [x0-12, x0+76) in LDS (zero outside
 // the image), every lane reads its own 19-pixel window and forms the S+3
 // row-blurred values of its column (xblurMultiKernel's chain), which are then
 // scattered into the column ring exactly as col_blur_dog_kernel does
-// (yblurKernel's chain).  Source rows are fetched FZ_PF rows ahead into
-// registers; the LDS row buffer has two slots so the write of row r+1 is
-// issued a whole step before its first read.
+// (yblurKernel's chain).
+//
+// Memory pipeline.  On gfx9-family hardware loads and stores retire through
+// one in-order counter, so a wave can only leave loads in flight across its
+// stores if the compiler can count both exactly.  The steady-state chunk of 20
+// rows is therefore straight-line code: every load and every store is issued
+// unconditionally (addresses are clamped, values are zeroed by selects, all 64
+// lanes store -- columns [w, pitch) of the destination planes are scratch).
+// Source rows are fetched FZ_PF rows ahead into registers; the LDS row buffer
+// has two slots so the write of row r+1 is issued a whole step before its
+// first read.
+//
+// SRC_MODE 0: source is an image with 16-byte aligned rows (float4 fetch)
+//          1: any pitch / alignment (scalar fetch)
+//          2: source is the previous octave's blur plane S, read at even rows
+//             and even columns (resizeKernel cudaSiftD.cu:544-559 folded into
+//             the fetch; the down-sampled base is never materialised)
 // ---------------------------------------------------------------------------
 constexpr int FZ_PF = 4;
 constexpr int FZ_STAGE = 88; // floats staged per row
-constexpr int FZ_LOADERS = FZ_STAGE / 4;
 
-template <int S, bool ALIGNED>
-__global__ __launch_bounds__(64) void pyramid_kernel(
-    const float *__restrict__ src, int src_pitch, long src_stride, float *__restrict__ blur,
-    long blur_stride, float *__restrict__ dog, long dog_stride, float *__restrict__ next_base,
-    long next_stride, int next_p, int w, int p, int h, int rows, hl_taps taps)
+template <int S, int SRC_MODE>
+__global__ __launch_bounds__(64, 3) void pyramid_kernel(
+    const float *__restrict__ src, int src_w, int src_h, int src_pitch, long src_stride,
+    float *__restrict__ blur, long blur_stride, float *__restrict__ dog, long dog_stride, int w,
+    int p, int h, int rows, hl_taps taps)
 {
     constexpr int NP = S + 3;
     __shared__ float lds[2][96];
     const int lane = threadIdx.x;
     const int x0 = blockIdx.x * 64;
-    const int x = x0 + lane;
-    const bool col_ok = x < w;
     const int y0 = blockIdx.y * rows;
     const int y1 = min(y0 + rows, h);
     const int nin = (y1 - y0) + 2 * RADIUS;
     const long plane = (long)p * h;
     const int z = blockIdx.z;
     src += z * src_stride;
-    float *bl = blur + z * blur_stride + x;
-    float *dg = dog + z * dog_stride + x;
-    float *nb = (next_base && !(x & 1)) ? next_base + z * next_stride + (x >> 1) : nullptr;
+    // destination of the next completed output row; advanced row by row (a
+    // loop-carried pointer: offsets formed from the unrolled row index would be
+    // hoisted out of the loop as dozens of live scalars)
+    float *bl = blur + z * blur_stride + x0 + lane + (long)y0 * p;
+    float *dg = dog + z * dog_stride + x0 + lane + (long)y0 * p;
 
-    // source fetch of one row: ALIGNED: lanes 0..21 one float4 each;
-    // otherwise every lane one float and lanes 0..23 a second one
-    const int xs = ALIGNED ? x0 - 12 + 4 * lane : x0 - 12 + lane;
-    auto fetch = [&](int r) -> float4 {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int yi = y0 - RADIUS + r;
-        if (r < nin && yi >= 0 && yi < h) { // wave-uniform
-            const float *row = src + (long)yi * src_pitch;
-            if (ALIGNED) {
-                if (lane < FZ_LOADERS && xs >= 0 && xs < w) {
-                    v = *reinterpret_cast<const float4 *>(row + xs);
-                    if (xs + 1 >= w) v.y = 0.f;
-                    if (xs + 2 >= w) v.z = 0.f;
-                    if (xs + 3 >= w) v.w = 0.f;
-                }
-            } else {
-                if (xs >= 0 && xs < w) v.x = row[xs];
-                if (lane < FZ_STAGE - 64 && xs + 64 >= 0 && xs + 64 < w) v.y = row[xs + 64];
-            }
+    // ---- source fetch of one row into registers ----
+    // mode 0: lane j < 22 holds staged floats 4j..4j+3
+    // mode 1: lane j holds staged float j (.x) and, j < 24, staged float 64+j (.y)
+    // mode 2: lane j < 44 holds staged floats 2j (.x) and 2j+1 (.z)
+    // The loads are unconditional (clamped addresses) and pixels outside the
+    // image are zeroed with bit masks, not selects: a select on the loaded
+    // value lets the compiler sink the load under the condition and wait for
+    // it on the spot, which would serialise the whole memory pipeline.
+    int col_off[2];
+    unsigned col_mask[4];
+    if (SRC_MODE == 0) {
+        const int xs = x0 - 12 + 4 * min(lane, FZ_STAGE / 4 - 1); // multiple of 4
+        const bool ok = xs >= 0 && xs < w;
+        col_off[0] = ok ? xs : 0;
+        col_off[1] = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) col_mask[q] = (ok && xs + q < w) ? 0xffffffffu : 0u;
+    } else if (SRC_MODE == 1) {
+        const int xa = x0 - 12 + lane, xb = xa + 64;
+        const bool oka = xa >= 0 && xa < w, okb = xb >= 0 && xb < w;
+        col_off[0] = oka ? xa : 0;
+        col_off[1] = okb ? xb : 0;
+        col_mask[0] = oka ? 0xffffffffu : 0u;
+        col_mask[1] = okb ? 0xffffffffu : 0u;
+        col_mask[2] = col_mask[3] = 0u;
+    } else {
+        const int xa = x0 - 12 + 2 * min(lane, FZ_STAGE / 2 - 1); // staged column (even), source column 2*xa
+        const bool ok = xa >= 0 && xa < w;
+        col_off[0] = ok ? 2 * xa : 0;
+        col_off[1] = 0;
+        col_mask[0] = ok ? 0xffffffffu : 0u;
+        col_mask[2] = (ok && xa + 1 < w) ? 0xffffffffu : 0u;
+        col_mask[1] = col_mask[3] = 0u;
+    }
+    auto masked = [](float v, unsigned m) { return __uint_as_float(__float_as_uint(v) & m); };
+    int yi_next = y0 - RADIUS; // rows are fetched strictly in order
+    auto fetch = [&]() __attribute__((always_inline)) -> float4 {
+        const int yi = yi_next++;
+        const unsigned row_mask = (yi >= 0 && yi < h) ? 0xffffffffu : 0u; // wave-uniform
+        const int yc = min(max(yi, 0), h - 1);
+        float4 v;
+        if (SRC_MODE == 1) {
+            const float *row = src + (long)yc * src_pitch;
+            v = make_float4(row[col_off[0]], row[col_off[1]], 0.f, 0.f);
+        } else {
+            const long yrow = SRC_MODE == 2 ? 2L * yc : (long)yc;
+            v = *reinterpret_cast<const float4 *>(src + yrow * src_pitch + col_off[0]);
         }
+        v.x = masked(v.x, col_mask[0] & row_mask);
+        v.y = masked(v.y, col_mask[1] & row_mask);
+        v.z = masked(v.z, col_mask[2] & row_mask);
+        v.w = masked(v.w, col_mask[3] & row_mask);
         return v;
     };
-    auto stage = [&](int slot, const float4 &v) {
-        if (ALIGNED) {
-            if (lane < FZ_LOADERS) *reinterpret_cast<float4 *>(&lds[slot][4 * lane]) = v;
-        } else {
+    auto stage = [&](int slot, const float4 &v) __attribute__((always_inline)) {
+        if (SRC_MODE == 0) {
+            if (lane < FZ_STAGE / 4) *reinterpret_cast<float4 *>(&lds[slot][4 * lane]) = v;
+        } else if (SRC_MODE == 1) {
             lds[slot][lane] = v.x;
             if (lane < FZ_STAGE - 64) lds[slot][lane + 64] = v.y;
+        } else {
+            if (lane < FZ_STAGE / 2) *reinterpret_cast<float2 *>(&lds[slot][2 * lane]) = make_float2(v.x, v.z);
         }
     };
 
@@ -286,18 +333,25 @@ __global__ __launch_bounds__(64) void pyramid_kernel(
 
     float4 g[FZ_PF];
 #pragma unroll
-    for (int q = 0; q < FZ_PF; ++q) g[q] = fetch(q);
+    for (int q = 0; q < FZ_PF; ++q) g[q] = fetch();
     stage(0, g[0]);
-    g[0] = fetch(FZ_PF);
+    g[0] = fetch();
 
-    for (int rb = 0; rb < nin; rb += COL_RING) {
-        static_for<COL_RING>([&](auto rr_c) {
+    // One chunk of 20 input rows.  GUARD = false is the steady state: straight
+    // line, every row completes one output row.  GUARD = true also serves the
+    // first chunk of a strip (rows 0..17 complete no output) and the last one
+    // (which may run past the strip's last input row) with run-time tests.
+    auto chunk = [&](auto guard_c, const int rb) __attribute__((always_inline)) {
+        constexpr bool GUARD = decltype(guard_c)::value;
+        static_for<COL_RING>([&](auto rr_c) __attribute__((always_inline)) {
             constexpr int rr = decltype(rr_c)::value;
             const int r = rb + rr;
-            // row r+1 goes to the other slot; its register is refilled with row r+1+FZ_PF
+            // keep each row's instructions together
+            __builtin_amdgcn_sched_barrier(0);
+            // row r+1 goes to the other LDS slot; its register is refilled with row r+1+FZ_PF
             stage((rr + 1) & 1, g[(rr + 1) % FZ_PF]);
-            g[(rr + 1) % FZ_PF] = fetch(r + 1 + FZ_PF);
-            if (r < nin) {
+            g[(rr + 1) % FZ_PF] = fetch();
+            if (!GUARD || r < nin) {
                 float win[TAPS];
 #pragma unroll
                 for (int k = 0; k < TAPS; ++k) win[k] = lds[rr & 1][lane + 3 + k];
@@ -317,22 +371,27 @@ __global__ __launch_bounds__(64) void pyramid_kernel(
                         acc[i][slot] = __builtin_fmaf(tap(taps, i, k), v[i], k == 0 ? 0.f : acc[i][slot]);
                     }
                 }
-                if (r >= 2 * RADIUS && col_ok) { // output row yo = y0 + r - 18 is complete
-                    const int yo = y0 + r - 2 * RADIUS;
+                if (!GUARD || r >= 2 * RADIUS) { // output row y0 + r - 18 is complete
                     const int e = (rr - 2 * RADIUS + COL_RING) % COL_RING;
                     float b[NP];
 #pragma unroll
                     for (int i = 0; i < NP; ++i) b[i] = acc[i][e];
-                    const long off = (long)yo * p;
 #pragma unroll
-                    for (int i = 1; i <= S; ++i) bl[(i - 1) * plane + off] = b[i];
+                    for (int i = 1; i <= S; ++i) bl[(i - 1) * plane] = b[i];
 #pragma unroll
-                    for (int i = 0; i < NP - 1; ++i) dg[i * plane + off] = b[i] - b[i + 1];
-                    if (nb && !(yo & 1)) nb[(long)(yo >> 1) * next_p] = b[S];
+                    for (int i = 0; i < NP - 1; ++i) dg[i * plane] = b[i] - b[i + 1];
+                    bl += p;
+                    dg += p;
                 }
             }
         });
-    }
+    };
+    // (the two guarded chunks are separate call sites on purpose: one loop that
+    // branches between the two bodies makes the register allocator spill)
+    chunk(std::true_type{}, 0);
+    int rb = COL_RING;
+    for (; rb + COL_RING <= nin; rb += COL_RING) chunk(std::false_type{}, rb);
+    if (rb < nin) chunk(std::true_type{}, rb);
 }
 
 // ---------------------------------------------------------------------------
@@ -1037,31 +1096,42 @@ int hl_col_blur_dog(const float *tmp, long tmp_stride, float *blur, long blur_st
     return launch_status();
 }
 
-int hl_pyramid(const float *src, int src_pitch, long src_stride, float *blur, long blur_stride,
-               float *dog, long dog_stride, float *next_base, long next_stride, int next_p, int w,
-               int p, int h, int n_scales, int nimg, const hl_taps *taps, void *stream)
+int hl_pyramid(const float *src, int src_w, int src_h, int src_pitch, long src_stride, int subsample,
+               float *blur, long blur_stride, float *dog, long dog_stride, int w, int p, int h,
+               int n_scales, int nimg, const hl_taps *taps, void *stream)
 {
-    if (w <= 0 || h <= 0 || nimg <= 0 || p < w || src_pitch < w || !src || !blur || !dog) return -1001;
-    if (next_base && next_p < (w + 1) / 2) return -1003;
+    if (w <= 0 || h <= 0 || nimg <= 0 || !src || !blur || !dog) return -1001;
+    if (p < w || (p & 63)) return -1005; // all 64 lanes of a block store: the pitch must cover them
     const bool aligned = ((src_pitch & 3) == 0) && ((((size_t)src) & 15) == 0) && ((src_stride & 3) == 0);
+    if (subsample) {
+        if (w != (src_w + 1) / 2 || h != (src_h + 1) / 2 || src_pitch < src_w || !aligned ||
+            src_pitch < ((src_w + 3) & ~3))
+            return -1006;
+    } else if (w != src_w || h != src_h || src_pitch < src_w) {
+        return -1006;
+    }
     int m = 6; // strip height 20*m - 18, as in hl_col_blur_dog
     while (m > 2 && (long)idivup(w, 64) * idivup(h, COL_RING * m - 2 * RADIUS) * nimg < 2048) --m;
     const int rows = COL_RING * m - 2 * RADIUS;
     dim3 grid(idivup(w, 64), idivup(h, rows), nimg), block(64);
     hipStream_t s = (hipStream_t)stream;
+    const int mode = subsample ? 2 : (aligned ? 0 : 1);
     ScopedTimer t(4, s);
-#define PYR_LAUNCH(SS, AL)                                                                        \
-    hipLaunchKernelGGL((pyramid_kernel<SS, AL>), grid, block, 0, s, src, src_pitch, src_stride,   \
-                       blur, blur_stride, dog, dog_stride, next_base, next_stride, next_p, w, p,  \
-                       h, rows, *taps)
-    if (n_scales == 2 && aligned)
-        PYR_LAUNCH(2, true);
+#define PYR_LAUNCH(SS, MD)                                                                         \
+    hipLaunchKernelGGL((pyramid_kernel<SS, MD>), grid, block, 0, s, src, src_w, src_h, src_pitch,  \
+                       src_stride, blur, blur_stride, dog, dog_stride, w, p, h, rows, *taps)
+    if (n_scales == 2 && mode == 0)
+        PYR_LAUNCH(2, 0);
+    else if (n_scales == 2 && mode == 1)
+        PYR_LAUNCH(2, 1);
     else if (n_scales == 2)
-        PYR_LAUNCH(2, false);
-    else if (n_scales == 3 && aligned)
-        PYR_LAUNCH(3, true);
+        PYR_LAUNCH(2, 2);
+    else if (n_scales == 3 && mode == 0)
+        PYR_LAUNCH(3, 0);
+    else if (n_scales == 3 && mode == 1)
+        PYR_LAUNCH(3, 1);
     else if (n_scales == 3)
-        PYR_LAUNCH(3, false);
+        PYR_LAUNCH(3, 2);
     else
         return -1002;
 #undef PYR_LAUNCH

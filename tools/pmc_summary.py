@@ -11,7 +11,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ("row_blur", "col_blur_dog", "detect", "keypoint", "finalize", "fillBuffer", "copyBuffer",
+    for k in ("pyramid", "row_blur", "col_blur_dog", "detect", "keypoint", "finalize", "fillBuffer", "copyBuffer",
               "subtract", "hessian", "gradient"):
         if k in name:
             return k
