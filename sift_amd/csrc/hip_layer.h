@@ -18,9 +18,10 @@ extern "C" {
 #define HL_MAX_OCT 8
 #define HL_MAX_GROUPS 32 /* (octave, scale) pairs */
 
-/* blur taps folded by symmetry: u[i][m] = c[i*19 + m], m = 0..9 */
+/* blur taps folded by symmetry and interleaved by plane:
+ * t[m][i] = c[i*19 + m], m = 0..9, i = plane (padded to 8) */
 typedef struct {
-    float u[HL_MAX_PLANES][HL_HALF_TAPS];
+    float t[HL_HALF_TAPS][8];
 } hl_taps;
 
 /* geometry of one octave inside a per-image arena (offsets in floats) */

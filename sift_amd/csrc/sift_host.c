@@ -101,6 +101,7 @@ static void gaussian1D(float *taps, float sigma, int n)
 
 static int build_tables(void)
 {
+    memset(&g_taps, 0, sizeof g_taps);
     const int S = g_params.n_scales;
     const float k = (float)pow(2, 0.5); /* cudaSiftH.cu:131 */
     for (int i = 0; i < S + 3; ++i) {   /* cudaSiftH.cu:135-139 */
@@ -118,7 +119,7 @@ static int build_tables(void)
                 set_err("blur taps of plane %d are not symmetric", i);
                 return -1;
             }
-            g_taps.u[i][m] = g_blur[i * HL_TAPS + m];
+            g_taps.t[m][i] = g_blur[i * HL_TAPS + m];
         }
     for (int q = 0; q < 32; ++q) { /* the 32 orientations the detector can assign */
         const double rad = (double)(11.25f * (float)q) * (3.14159265358979323846 / 180.0);

@@ -38,9 +38,24 @@ __device__ __forceinline__ void static_for(F &&f)
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
+// blur tap k (0..18) of plane `plane`; the table stores the 10 distinct values
+// of each symmetric kernel with the planes interleaved, so the taps of planes
+// (2j, 2j+1) sit in one aligned scalar register pair
 __device__ __forceinline__ float tap(const hl_taps &t, int plane, int k)
 {
-    return t.u[plane][k <= 9 ? k : 18 - k];
+    return t.t[k <= 9 ? k : 18 - k][plane];
+}
+typedef float float2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float tap1(const hl_taps &t, int plane, int k) { return tap(t, plane, k); }
+__device__ __forceinline__ float2v tap2(const hl_taps &t, int pair, int k)
+{
+    const int m = k <= 9 ? k : 18 - k;
+    return float2v{t.t[m][2 * pair], t.t[m][2 * pair + 1]};
+}
+// two IEEE fused multiply-adds in one instruction (v_pk_fma_f32)
+__device__ __forceinline__ float2v pk_fma(float2v a, float2v b, float2v c)
+{
+    return __builtin_elementwise_fma(a, b, c);
 }
 
 // ---------------------------------------------------------------------------
@@ -229,8 +244,7 @@ __global__ __launch_bounds__(64) void col_blur_dog_kernel(
 // has two slots so the write of row r+1 is issued a whole step before its
 // first read.
 //
-// SRC_MODE 0: source is an image with 16-byte aligned rows (float4 fetch)
-//          1: any pitch / alignment (scalar fetch)
+// SRC_MODE 0: source is an image (any pitch or alignment)
 //          2: source is the previous octave's blur plane S, read at even rows
 //             and even columns (resizeKernel cudaSiftD.cu:544-559 folded into
 //             the fetch; the down-sampled base is never materialised)
@@ -239,13 +253,13 @@ constexpr int FZ_PF = 4;
 constexpr int FZ_STAGE = 88; // floats staged per row
 
 template <int S, int SRC_MODE>
-__global__ __launch_bounds__(64, 3) void pyramid_kernel(
+__global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     const float *__restrict__ src, int src_w, int src_h, int src_pitch, long src_stride,
     float *__restrict__ blur, long blur_stride, float *__restrict__ dog, long dog_stride, int w,
     int p, int h, int rows, hl_taps taps)
 {
     constexpr int NP = S + 3;
-    __shared__ float lds[2][96];
+    __shared__ float lds[2][128];
     const int lane = threadIdx.x;
     const int x0 = blockIdx.x * 64;
     const int y0 = blockIdx.y * rows;
@@ -254,11 +268,22 @@ __global__ __launch_bounds__(64, 3) void pyramid_kernel(
     const long plane = (long)p * h;
     const int z = blockIdx.z;
     src += z * src_stride;
+    // buffer descriptors (wave-uniform): 32-bit per-lane offsets in one VGPR and
+    // per-row / per-plane offsets in scalar registers replace 64-bit per-lane
+    // address arithmetic
+    const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(src), 0, (int)(unsigned)min((long)src_pitch * src_h * 4, 0xffffffffL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t bl_rs = __builtin_amdgcn_make_buffer_rsrc(
+        blur + z * blur_stride, 0, (int)(unsigned)min(plane * S * 4, 0xffffffffL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t dg_rs = __builtin_amdgcn_make_buffer_rsrc(
+        dog + z * dog_stride, 0, (int)(unsigned)min(plane * (S + 2) * 4, 0xffffffffL), 0x00020000);
     // destination of the next completed output row; advanced row by row (a
     // loop-carried pointer: offsets formed from the unrolled row index would be
     // hoisted out of the loop as dozens of live scalars)
-    float *bl = blur + z * blur_stride + x0 + lane + (long)y0 * p;
-    float *dg = dog + z * dog_stride + x0 + lane + (long)y0 * p;
+    // byte offsets are unsigned 32-bit (the launcher checks the planes fit)
+    const int out_lane = (x0 + lane) * 4;         // this lane's column
+    unsigned out_row = (unsigned)y0 * p * 4u;     // the next completed output row
+    const unsigned plane_b = (unsigned)plane * 4u;
 
     // ---- source fetch of one row into registers ----
     // mode 0: lane j < 22 holds staged floats 4j..4j+3
@@ -268,70 +293,50 @@ __global__ __launch_bounds__(64, 3) void pyramid_kernel(
     // image are zeroed with bit masks, not selects: a select on the loaded
     // value lets the compiler sink the load under the condition and wait for
     // it on the spot, which would serialise the whole memory pipeline.
+    // lane j holds staged float j (.x) and, for j < 24, staged float 64+j (.y)
+    constexpr int SX = SRC_MODE == 2 ? 2 : 1; // column and row step in the source
     int col_off[2];
-    unsigned col_mask[4];
-    if (SRC_MODE == 0) {
-        const int xs = x0 - 12 + 4 * min(lane, FZ_STAGE / 4 - 1); // multiple of 4
-        const bool ok = xs >= 0 && xs < w;
-        col_off[0] = ok ? xs : 0;
-        col_off[1] = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) col_mask[q] = (ok && xs + q < w) ? 0xffffffffu : 0u;
-    } else if (SRC_MODE == 1) {
+    unsigned col_mask[2];
+    {
         const int xa = x0 - 12 + lane, xb = xa + 64;
-        const bool oka = xa >= 0 && xa < w, okb = xb >= 0 && xb < w;
-        col_off[0] = oka ? xa : 0;
-        col_off[1] = okb ? xb : 0;
+        const bool oka = xa >= 0 && xa < w, okb = lane < FZ_STAGE - 64 && xb >= 0 && xb < w;
+        col_off[0] = oka ? SX * xa * 4 : 0;
+        col_off[1] = okb ? SX * xb * 4 : 0;
         col_mask[0] = oka ? 0xffffffffu : 0u;
         col_mask[1] = okb ? 0xffffffffu : 0u;
-        col_mask[2] = col_mask[3] = 0u;
-    } else {
-        const int xa = x0 - 12 + 2 * min(lane, FZ_STAGE / 2 - 1); // staged column (even), source column 2*xa
-        const bool ok = xa >= 0 && xa < w;
-        col_off[0] = ok ? 2 * xa : 0;
-        col_off[1] = 0;
-        col_mask[0] = ok ? 0xffffffffu : 0u;
-        col_mask[2] = (ok && xa + 1 < w) ? 0xffffffffu : 0u;
-        col_mask[1] = col_mask[3] = 0u;
     }
-    auto masked = [](float v, unsigned m) { return __uint_as_float(__float_as_uint(v) & m); };
+    auto masked = [](float v, unsigned m) __attribute__((always_inline)) { return __uint_as_float(__float_as_uint(v) & m); };
     int yi_next = y0 - RADIUS; // rows are fetched strictly in order
-    auto fetch = [&]() __attribute__((always_inline)) -> float4 {
+    // The loaded value is only touched when it is staged, FZ_PF rows later; the
+    // row's validity travels beside it as a wave-uniform mask.
+    struct Row { float2v v; unsigned ok; };
+    auto fetch = [&]() __attribute__((always_inline)) -> Row {
         const int yi = yi_next++;
-        const unsigned row_mask = (yi >= 0 && yi < h) ? 0xffffffffu : 0u; // wave-uniform
         const int yc = min(max(yi, 0), h - 1);
-        float4 v;
-        if (SRC_MODE == 1) {
-            const float *row = src + (long)yc * src_pitch;
-            v = make_float4(row[col_off[0]], row[col_off[1]], 0.f, 0.f);
-        } else {
-            const long yrow = SRC_MODE == 2 ? 2L * yc : (long)yc;
-            v = *reinterpret_cast<const float4 *>(src + yrow * src_pitch + col_off[0]);
-        }
-        v.x = masked(v.x, col_mask[0] & row_mask);
-        v.y = masked(v.y, col_mask[1] & row_mask);
-        v.z = masked(v.z, col_mask[2] & row_mask);
-        v.w = masked(v.w, col_mask[3] & row_mask);
-        return v;
+        const int row = (int)((unsigned)(SX * yc) * (unsigned)src_pitch * 4u);
+        Row o;
+        o.v.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src_rs, col_off[0], row, 0));
+        o.v.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src_rs, col_off[1], row, 0));
+        o.ok = (yi >= 0 && yi < h) ? 0xffffffffu : 0u;
+        return o;
     };
-    auto stage = [&](int slot, const float4 &v) __attribute__((always_inline)) {
-        if (SRC_MODE == 0) {
-            if (lane < FZ_STAGE / 4) *reinterpret_cast<float4 *>(&lds[slot][4 * lane]) = v;
-        } else if (SRC_MODE == 1) {
-            lds[slot][lane] = v.x;
-            if (lane < FZ_STAGE - 64) lds[slot][lane + 64] = v.y;
-        } else {
-            if (lane < FZ_STAGE / 2) *reinterpret_cast<float2 *>(&lds[slot][2 * lane]) = make_float2(v.x, v.z);
-        }
+    auto stage = [&](int slot, const Row &o) __attribute__((always_inline)) {
+        lds[slot][lane] = masked(o.v.x, col_mask[0] & o.ok);
+        lds[slot][lane + 64] = masked(o.v.y, col_mask[1] & o.ok); // lanes >= 24 write unused cells
     };
 
-    float acc[NP][COL_RING];
+    constexpr int NPAIR = NP / 2;
+    constexpr bool ODD = (NP & 1) != 0;
+    float2v accp[NPAIR][COL_RING];
+    float accs[COL_RING];
 #pragma unroll
-    for (int i = 0; i < NP; ++i)
+    for (int k = 0; k < COL_RING; ++k) {
 #pragma unroll
-        for (int k = 0; k < COL_RING; ++k) acc[i][k] = 0.f;
+        for (int j = 0; j < NPAIR; ++j) accp[j][k] = float2v{0.f, 0.f};
+        accs[k] = 0.f;
+    }
 
-    float4 g[FZ_PF];
+    Row g[FZ_PF];
 #pragma unroll
     for (int q = 0; q < FZ_PF; ++q) g[q] = fetch();
     stage(0, g[0]);
@@ -354,45 +359,59 @@ __global__ __launch_bounds__(64, 3) void pyramid_kernel(
             if (!GUARD || r < nin) {
                 float win[TAPS];
 #pragma unroll
-                for (int k = 0; k < TAPS; ++k) win[k] = lds[rr & 1][lane + 3 + k];
-                float v[NP];
+                for (int k = 0; k < 10; ++k) win[k] = lds[rr & 1][lane + 3 + k];
+                float2v vp[NPAIR];
+                float vs = 0.f;
 #pragma unroll
-                for (int i = 0; i < NP; ++i) {
-                    float sum = 0.f;
+                for (int j = 0; j < NPAIR; ++j) vp[j] = float2v{0.f, 0.f};
 #pragma unroll
-                    for (int k = 0; k < TAPS; ++k) sum = __builtin_fmaf(tap(taps, i, k), win[k], sum);
-                    v[i] = sum;
+                for (int k = 0; k < TAPS; ++k) {
+                    if (k == 10) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int q = 10; q < TAPS; ++q) win[q] = lds[rr & 1][lane + 3 + q];
+                    }
+                    const float2v wk = float2v{win[k], win[k]};
+#pragma unroll
+                    for (int j = 0; j < NPAIR; ++j) vp[j] = pk_fma(tap2(taps, j, k), wk, vp[j]);
+                    if (ODD) vs = __builtin_fmaf(tap1(taps, NP - 1, k), win[k], vs);
                 }
 #pragma unroll
-                for (int i = 0; i < NP; ++i) {
+                for (int k = 0; k < TAPS; ++k) {
+                    const int slot = (rr - k + COL_RING) % COL_RING;
 #pragma unroll
-                    for (int k = 0; k < TAPS; ++k) {
-                        const int slot = (rr - k + COL_RING) % COL_RING;
-                        acc[i][slot] = __builtin_fmaf(tap(taps, i, k), v[i], k == 0 ? 0.f : acc[i][slot]);
-                    }
+                    for (int j = 0; j < NPAIR; ++j)
+                        accp[j][slot] = pk_fma(tap2(taps, j, k), vp[j], k == 0 ? float2v{0.f, 0.f} : accp[j][slot]);
+                    if (ODD) accs[slot] = __builtin_fmaf(tap1(taps, NP - 1, k), vs, k == 0 ? 0.f : accs[slot]);
                 }
                 if (!GUARD || r >= 2 * RADIUS) { // output row y0 + r - 18 is complete
                     const int e = (rr - 2 * RADIUS + COL_RING) % COL_RING;
                     float b[NP];
 #pragma unroll
-                    for (int i = 0; i < NP; ++i) b[i] = acc[i][e];
+                    for (int j = 0; j < NPAIR; ++j) {
+                        b[2 * j] = accp[j][e].x;
+                        b[2 * j + 1] = accp[j][e].y;
+                    }
+                    if (ODD) b[NP - 1] = accs[e];
 #pragma unroll
-                    for (int i = 1; i <= S; ++i) bl[(i - 1) * plane] = b[i];
+                    for (int i = 1; i <= S; ++i)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b[i]), bl_rs, out_lane,
+                                                              (int)(out_row + (i - 1) * plane_b), 0);
 #pragma unroll
-                    for (int i = 0; i < NP - 1; ++i) dg[i * plane] = b[i] - b[i + 1];
-                    bl += p;
-                    dg += p;
+                    for (int i = 0; i < NP - 1; ++i)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b[i] - b[i + 1]), dg_rs, out_lane,
+                                                              (int)(out_row + i * plane_b), 0);
+                    out_row += (unsigned)p * 4u;
                 }
             }
         });
     };
-    // (the two guarded chunks are separate call sites on purpose: one loop that
-    // branches between the two bodies makes the register allocator spill)
     chunk(std::true_type{}, 0);
     int rb = COL_RING;
     for (; rb + COL_RING <= nin; rb += COL_RING) chunk(std::false_type{}, rb);
     if (rb < nin) chunk(std::true_type{}, rb);
 }
+
 
 // ---------------------------------------------------------------------------
 // Detection.  The reference's acceptance rule depends on where a pixel sits in
@@ -1100,36 +1119,28 @@ int hl_pyramid(const float *src, int src_w, int src_h, int src_pitch, long src_s
                float *blur, long blur_stride, float *dog, long dog_stride, int w, int p, int h,
                int n_scales, int nimg, const hl_taps *taps, void *stream)
 {
-    if (w <= 0 || h <= 0 || nimg <= 0 || !src || !blur || !dog) return -1001;
+    if (w <= 0 || h <= 0 || nimg <= 0 || !src || !blur || !dog || src_pitch < src_w) return -1001;
     if (p < w || (p & 63)) return -1005; // all 64 lanes of a block store: the pitch must cover them
-    const bool aligned = ((src_pitch & 3) == 0) && ((((size_t)src) & 15) == 0) && ((src_stride & 3) == 0);
-    if (subsample) {
-        if (w != (src_w + 1) / 2 || h != (src_h + 1) / 2 || src_pitch < src_w || !aligned ||
-            src_pitch < ((src_w + 3) & ~3))
-            return -1006;
-    } else if (w != src_w || h != src_h || src_pitch < src_w) {
+    if (subsample ? (w != (src_w + 1) / 2 || h != (src_h + 1) / 2) : (w != src_w || h != src_h))
         return -1006;
-    }
+    // 32-bit byte offsets inside one image's source, blur and DoG planes
+    if ((long)p * h * (n_scales + 2) * 4 > 0xffffffffL || (long)src_pitch * src_h * 4 > 0xffffffffL)
+        return -1007;
     int m = 6; // strip height 20*m - 18, as in hl_col_blur_dog
     while (m > 2 && (long)idivup(w, 64) * idivup(h, COL_RING * m - 2 * RADIUS) * nimg < 2048) --m;
     const int rows = COL_RING * m - 2 * RADIUS;
     dim3 grid(idivup(w, 64), idivup(h, rows), nimg), block(64);
     hipStream_t s = (hipStream_t)stream;
-    const int mode = subsample ? 2 : (aligned ? 0 : 1);
     ScopedTimer t(4, s);
 #define PYR_LAUNCH(SS, MD)                                                                         \
     hipLaunchKernelGGL((pyramid_kernel<SS, MD>), grid, block, 0, s, src, src_w, src_h, src_pitch,  \
                        src_stride, blur, blur_stride, dog, dog_stride, w, p, h, rows, *taps)
-    if (n_scales == 2 && mode == 0)
+    if (n_scales == 2 && !subsample)
         PYR_LAUNCH(2, 0);
-    else if (n_scales == 2 && mode == 1)
-        PYR_LAUNCH(2, 1);
     else if (n_scales == 2)
         PYR_LAUNCH(2, 2);
-    else if (n_scales == 3 && mode == 0)
+    else if (n_scales == 3 && !subsample)
         PYR_LAUNCH(3, 0);
-    else if (n_scales == 3 && mode == 1)
-        PYR_LAUNCH(3, 1);
     else if (n_scales == 3)
         PYR_LAUNCH(3, 2);
     else
