@@ -192,7 +192,32 @@ def main():
         }
         if dom == "pyramid":
             out["roofline"]["two_pass_equivalent_GBps"] = achieved / 1e9 * ab["two_pass"] / ab["pyramid"]
+            out["roofline"]["note"] = ("the fused kernel is FP32 vector-issue bound (190 FMA/px); the HBM "
+                                       "fraction is quoted on its own 29 B/px, a two-pass design moves 69 B/px")
         out["kernels_ms_per_image"] = {k: v["ms_total"] / (args.batch * args.steps) for k, v in kern.items()}
+        # HBM-side bytes per launch of the dominant kernel from rocprofv3 counters (separate
+        # FETCH_SIZE / WRITE_SIZE passes over this same command, tools/prof_pmc.sh), if committed
+        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tf):
+            try:
+                t = json.load(open(tf)).get(kernel_names[dom])
+                if t and t.get("batch") == args.batch:
+                    out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+            except (ValueError, OSError):
+                pass
+        # the same kernels without the second launch set competing for the chip
+        if world == 1:
+            sift_amd.lib().sift_set_batch_lanes(1)
+            sift_amd.timing_reset()
+            sift_amd.timing_enable(True)
+            sift_amd.extract_batch(d_imgs, W, d_pts=d_pts)
+            sift_amd.timing_enable(False)
+            ms1, n1 = sift_amd.timing_read(names[dom])
+            if ms1 > 0:
+                a1 = ab[dom] * px * args.batch / (ms1 * 1e-3)
+                out["roofline_single_stream"] = {"kernel": kernel_names[dom], "achieved": a1 / 1e9,
+                                                 "frac": a1 / HBM_PEAK, "avg_launch_ms": ms1 / max(n1, 1)}
+            sift_amd.lib().sift_set_batch_lanes(args.lanes or 2)
         if world == 1 and not args.no_cpu_baseline:
             import oracle
 

@@ -98,7 +98,7 @@ void sift_shutdown(void);
 int sift_extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
                        const float *d_imgs, long img_stride, int n,
                        int width, int pitch, int height, void *stream);
-/* images worked on per launch set (default 8); arenas grow to match */
+/* images worked on per launch set (default 64); arenas grow to match */
 void sift_set_batch_chunk(int images_per_launch);
 /* launch sets in flight at once, each on a private stream and arena: 1 or 2
  * (default 2: the short kernels of the small octaves of one set overlap the

@@ -54,7 +54,7 @@ static unsigned *g_batch_count[MAX_DEV];
 static int g_batch_count_n[MAX_DEV];
 static int g_lanes = N_LANES;
 static unsigned *g_slot_counter[MAX_DEV]; /* device, SIFT_MAX_SLOTS words */
-static int g_chunk = 8;
+static int g_chunk = 64;
 static char g_err[512] = "";
 
 static void set_err(const char *fmt, ...)
