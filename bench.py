@@ -165,7 +165,8 @@ def main():
     if rank == 0:
         ab = algorithmic_bytes(S)
         px = sum(octave_pixels(W, H, O))
-        names = {"pyramid": sift_amd.K_PYRAMID, "detect": sift_amd.K_DETECT, "keypoint": sift_amd.K_KEYPOINT}
+        names = {"pyramid": sift_amd.K_PYRAMID, "alias": sift_amd.K_ALIAS, "verify": sift_amd.K_VERIFY,
+                 "detect": sift_amd.K_DETECT, "keypoint": sift_amd.K_KEYPOINT}
         kern = {}
         for name, kid in names.items():
             ms, n = sift_amd.timing_read(kid)

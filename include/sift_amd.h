@@ -100,6 +100,12 @@ int sift_extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
                        int width, int pitch, int height, void *stream);
 /* images worked on per launch set (default 64); arenas grow to match */
 void sift_set_batch_chunk(int images_per_launch);
+/* Detection is sparse: the pyramid pass queues the pixels that pass the contrast
+ * test and only those are examined further.  n = first-octave queue capacity per
+ * image and scale (default 65536; later octaves get a quarter each, at least
+ * 4096).  A queue that overflows is redone by the dense detector, so results do
+ * not depend on n; 0 disables the queues (dense detector only). */
+void sift_set_queue_cap(int n);
 /* launch sets in flight at once, each on a private stream and arena: 1 or 2
  * (default 2: the short kernels of the small octaves of one set overlap the
  * long kernels of the other) */
@@ -146,7 +152,9 @@ enum {
     SIFT_K_DETECT = 2,
     SIFT_K_KEYPOINT = 3,
     SIFT_K_PYRAMID = 4, /* fused row + column pass of the hot path */
-    SIFT_K_COUNT = 5
+    SIFT_K_VERIFY = 5,  /* sparse detector over queued contrast candidates */
+    SIFT_K_ALIAS = 6,   /* pre-filter of the rows the reference reads through aliased cells */
+    SIFT_K_COUNT = 7
 };
 /* When enabled, every launch of the pyramid kernels is bracketed by events on
  * its own stream; sift_timing_read drains them (synchronises). */

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsift_amd.so")
 
 MAX_SLOTS = 8
-K_ROW_BLUR, K_COL_BLUR_DOG, K_DETECT, K_KEYPOINT, K_PYRAMID = 0, 1, 2, 3, 4
+K_ROW_BLUR, K_COL_BLUR_DOG, K_DETECT, K_KEYPOINT, K_PYRAMID, K_VERIFY, K_ALIAS = 0, 1, 2, 3, 4, 5, 6
 
 # Sift/src/sift.h:7-13
 POINT_DTYPE = np.dtype(
@@ -63,6 +63,7 @@ SYMBOLS = {
     "sift_extract_batch": (C.c_int, [_vp, _vp, _ip, _vp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "sift_set_batch_chunk": (None, [C.c_int]),
     "sift_set_batch_lanes": (None, [C.c_int]),
+    "sift_set_queue_cap": (None, [C.c_int]),
     "sift_device_count": (C.c_int, []),
     "sift_set_device": (C.c_int, [C.c_int]),
     "sift_dev_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),

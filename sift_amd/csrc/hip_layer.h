@@ -27,8 +27,21 @@ typedef struct {
 /* geometry of one octave inside a per-image arena (offsets in floats) */
 typedef struct {
     int w, h, p;        /* internal pitch p */
+    int qcap;           /* capacity of each scale's contrast-candidate queue */
     long blur_off;      /* S kept blur planes (plane index 1..S) */
+    long dog_off;       /* S+2 DoG planes */
+    long queue_off;     /* first of the octave's S queues, in words, inside an image's queue block */
 } hl_octave;
+
+/* everything the detection kernels need to work on all octaves in one launch */
+typedef struct {
+    int n_scales, n_oct, cap;
+    float edge_limit;   /* (r_thresh^2)/r_thresh, cudaSiftD.cu:292 */
+    float contrast;     /* EXTREMA_THRESH, cudaSiftD.cu:293 */
+    hl_octave oct[HL_MAX_OCT];
+    int band0[HL_MAX_OCT + 1];  /* first 32-row band of each octave (alias pre-filter units) */
+    int dense0[HL_MAX_OCT + 1]; /* first 256x32-pixel block of each octave (dense detector units) */
+} hl_detect_args;
 
 typedef struct {
     int n_scales;
@@ -84,16 +97,32 @@ int hl_col_blur_dog(const float *tmp, long tmp_stride, float *blur, long blur_st
  * no intermediate in HBM.  subsample != 0: the source is the previous octave's
  * blur plane S (src_w x src_h) and is read at its even rows and columns, so
  * w = ceil(src_w/2), h = ceil(src_h/2).  p must be a multiple of 64: columns
- * [w, p) of the destination planes are written with don't-care values. */
+ * [w, p) of the destination planes are written with don't-care values.
+ * queue != NULL: pixels passing the detector's contrast and border tests (rows
+ * with y mod 32 >= 30 excepted) are queued per scale: entry (x | y<<16) at
+ * queue[i*qcap + k], count in qcount[group0 + i]; a count above qcap means the
+ * queue is incomplete and the dense detector must redo that scale. */
 int hl_pyramid(const float *src, int src_w, int src_h, int src_pitch, long src_stride, int subsample,
                float *blur, long blur_stride, float *dog, long dog_stride, int w, int p, int h,
-               int n_scales, int nimg, const hl_taps *taps, void *stream);
-/* appends (x | y<<16) of accepted pixels of scales 0..S-1 to
- * cand + (group0+i)*cap, counting in counts[group0+i] */
-int hl_detect(const float *dog, long dog_stride, const float *blur, long blur_stride, int w,
-              int p, int h, int n_scales, float r_thresh, float extrema_thresh,
-              unsigned *cand, long cand_stride, unsigned *counts, long counts_stride,
-              int group0, int cap, int nimg, void *stream);
+               int n_scales, int nimg, const hl_taps *taps, float contrast, unsigned *queue,
+               long queue_stride, unsigned *qcount, long qcount_stride, int qcap, int group0,
+               void *stream);
+/* The three detection launches cover every octave of the launch set.
+ * hl_alias_prefilter: queues the pixels whose centre value the reference reads
+ *   through an aliased shared-memory cell (y mod 32 in {30,31}).
+ * hl_verify: rank + edge tests over the queues; accepted pixels are appended as
+ *   (x | y<<16) to cand + group*cap, counted in counts[group].
+ * hl_detect: the dense detector; with gate set (the queue counters) it only
+ *   redoes the groups whose queue overflowed, with gate NULL it does everything. */
+int hl_alias_prefilter(const float *arena, long arena_stride, unsigned *queue, long queue_stride,
+                       unsigned *qcount, long qcount_stride, const hl_detect_args *a, int nimg,
+                       void *stream);
+int hl_verify(const float *arena, long arena_stride, const unsigned *queue, long queue_stride,
+              const unsigned *qcount, long qcount_stride, unsigned *cand, long cand_stride,
+              unsigned *counts, long counts_stride, const hl_detect_args *a, int nimg, void *stream);
+int hl_detect(const float *arena, long arena_stride, unsigned *cand, long cand_stride,
+              unsigned *counts, long counts_stride, const unsigned *gate, long gate_stride,
+              const hl_detect_args *a, int nimg, void *stream);
 /* orientation + descriptor for every candidate; writes SiftPoint records
  * behind base_count[z] and meta (may be NULL) */
 int hl_keypoints(void *pts, long pts_stride_points, unsigned char *meta, const float *arena,

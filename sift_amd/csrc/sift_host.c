@@ -20,20 +20,26 @@
 #define MAX_DEV 16
 #define BATCH_SLOT SIFT_MAX_SLOTS /* two batch arenas follow the stream slots */
 #define N_LANES 2
+#define QUEUE_CAP 65536 /* first-octave contrast candidates per image and scale before the dense fall-back */
+#define QUEUE_MIN 4096
+#define COUNT_WORDS (2 * HL_MAX_GROUPS)
 
 /* ---- state ---------------------------------------------------------------- */
 typedef struct {
     int valid;
     /* signature the arena was planned for */
-    int w, h, S, O, oct0, cap, nimg;
+    int w, h, S, O, oct0, cap, nimg, queue_cap;
     float *arena;
     long arena_stride; /* floats per image */
-    long dog_off;
     int ow[SIFT_MAX_OCTAVES], oh[SIFT_MAX_OCTAVES], op[SIFT_MAX_OCTAVES];
-    long blur_off[SIFT_MAX_OCTAVES];
-    unsigned *counts; /* nimg * HL_MAX_GROUPS */
+    long blur_off[SIFT_MAX_OCTAVES], dog_off[SIFT_MAX_OCTAVES];
+    long queue_off[SIFT_MAX_OCTAVES]; /* words, inside one image's queue block */
+    int qcap[SIFT_MAX_OCTAVES];
+    long queue_stride;                /* words per image */
+    unsigned *counts; /* nimg * 2 * HL_MAX_GROUPS: accepted per group, then queued per group */
     unsigned *cand;   /* nimg * groups * cap */
     long cand_stride;
+    unsigned *queue;  /* nimg * queue_stride: contrast candidates per octave and scale */
     void *last_stream;
 } slot_ctx;
 
@@ -55,6 +61,7 @@ static int g_batch_count_n[MAX_DEV];
 static int g_lanes = N_LANES;
 static unsigned *g_slot_counter[MAX_DEV]; /* device, SIFT_MAX_SLOTS words */
 static int g_chunk = 64;
+static int g_queue_cap = QUEUE_CAP; /* 0: no pre-filter, dense detector only */
 static char g_err[512] = "";
 
 static void set_err(const char *fmt, ...)
@@ -182,6 +189,12 @@ void sift_get_tables(float *blur, float *wnd, float *desc)
     memcpy(desc, g_desc, sizeof(float) * 16);
 }
 
+void sift_set_queue_cap(int n)
+{
+    if (n >= 0 && n <= (1 << 24))
+        g_queue_cap = n;
+}
+
 void sift_set_batch_chunk(int n)
 {
     if (n >= 1 && n <= 1024)
@@ -194,6 +207,7 @@ static void free_slot(slot_ctx *c)
     if (c->arena) hl_free(c->arena);
     if (c->counts) hl_free(c->counts);
     if (c->cand) hl_free(c->cand);
+    if (c->queue) hl_free(c->queue);
     memset(c, 0, sizeof *c);
 }
 
@@ -242,14 +256,16 @@ static int ensure_slot_counter(int dev)
     return 0;
 }
 
-/* Plans (or re-plans) the per-image arena: first-octave sized DoG scratch shared
- * by all octaves and S kept blur planes per octave (planes 1..S: the Hessian,
- * the gradients and the next octave read nothing else). */
+/* Plans (or re-plans) the per-image arena: per octave the S+2 DoG planes and the
+ * S kept blur planes (1..S: the Hessian, the gradients and the next octave read
+ * nothing else).  Every octave has its own DoG planes so that all pyramid
+ * passes can be queued back to back and detection can run once, over all
+ * octaves, afterwards. */
 static int ensure_arena(slot_ctx *c, int w, int h, int oct0, int nimg)
 {
     const int S = g_params.n_scales, O = g_params.n_octaves, cap = g_params.max_points;
     if (c->valid && c->w == w && c->h == h && c->S == S && c->O == O && c->oct0 == oct0 &&
-        c->cap == cap && c->nimg >= nimg)
+        c->cap == cap && c->nimg >= nimg && c->queue_cap == g_queue_cap)
         return 0;
     if (c->valid) { /* geometry changed: drain the slot before its memory goes away */
         int r = hl_stream_sync(c->last_stream);
@@ -257,30 +273,37 @@ static int ensure_arena(slot_ctx *c, int w, int h, int oct0, int nimg)
     }
     free_slot(c);
 
-    long off = 0;
-    int ww = w, hh = h;
-    const int p0 = ialignup(w, 64);
-    c->dog_off = off;
-    off += lalign((long)p0 * h * (S + 2), 64);
+    long off = 0, qoff = 0;
+    int ww = w, hh = h, qc = g_queue_cap > 0 ? g_queue_cap : 1;
     for (int o = oct0; o < O; ++o) {
         const int oi = o - oct0;
         c->ow[oi] = ww;
         c->oh[oi] = hh;
-        c->op[oi] = (o == oct0) ? p0 : ialignup(ww, 128); /* cudaSiftH.cu:46 */
+        c->op[oi] = (o == oct0) ? ialignup(ww, 64) : ialignup(ww, 128); /* cudaSiftH.cu:46 */
+        c->dog_off[oi] = off;
+        off += lalign((long)c->op[oi] * hh * (S + 2), 64);
         c->blur_off[oi] = off;
         off += lalign((long)c->op[oi] * hh * S, 64);
+        c->qcap[oi] = qc;
+        c->queue_off[oi] = qoff;
+        qoff += (long)S * qc;
+        if (qc > QUEUE_MIN) qc = qc / 4 < QUEUE_MIN ? QUEUE_MIN : qc / 4;
         ww = idivup(ww, 2); /* cudaSiftH.cu:44-45 */
         hh = idivup(hh, 2);
     }
+    c->queue_stride = qoff;
     c->arena_stride = off;
     const int groups = (O - oct0) * S;
     void *p = NULL;
     int r = hl_malloc(&p, sizeof(float) * (size_t)off * nimg);
     if (r) return fail_hl(r, "allocating arena");
     c->arena = (float *)p;
-    r = hl_malloc(&p, sizeof(unsigned) * HL_MAX_GROUPS * (size_t)nimg);
+    r = hl_malloc(&p, sizeof(unsigned) * COUNT_WORDS * (size_t)nimg);
     if (r) return fail_hl(r, "allocating group counters");
     c->counts = (unsigned *)p;
+    r = hl_malloc(&p, sizeof(unsigned) * (size_t)c->queue_stride * nimg);
+    if (r) return fail_hl(r, "allocating candidate queue");
+    c->queue = (unsigned *)p;
     c->cand_stride = (long)groups * cap;
     r = hl_malloc(&p, sizeof(unsigned) * (size_t)c->cand_stride * nimg);
     if (r) return fail_hl(r, "allocating candidate lists");
@@ -292,6 +315,7 @@ static int ensure_arena(slot_ctx *c, int w, int h, int oct0, int nimg)
     c->oct0 = oct0;
     c->cap = cap;
     c->nimg = nimg;
+    c->queue_cap = g_queue_cap;
     c->valid = 1;
     return 0;
 }
@@ -305,26 +329,57 @@ static int enqueue_extract(slot_ctx *c, SiftPoint *pts, unsigned char *meta, con
                            void *stream)
 {
     const int S = g_params.n_scales, O = g_params.n_octaves, cap = g_params.max_points;
-    int r = hl_memset_async(c->counts, 0, sizeof(unsigned) * HL_MAX_GROUPS * nimg, stream);
+    int r = hl_memset_async(c->counts, 0, sizeof(unsigned) * COUNT_WORDS * nimg, stream);
     if (r) return fail_hl(r, "resetting group counters");
     float *A = c->arena;
     const long AS = c->arena_stride;
+    unsigned *queued = c->counts + HL_MAX_GROUPS; /* second half of each image's counter block */
+    const int prefilter = c->queue_cap > 0;
+    hl_detect_args da;
+    memset(&da, 0, sizeof da);
+    da.n_scales = S;
+    da.n_oct = O - oct0;
+    da.cap = cap;
+    da.edge_limit = (g_params.r_thresh * g_params.r_thresh) / g_params.r_thresh; /* cudaSiftD.cu:292 */
+    da.contrast = g_params.extrema_thresh;
     for (int o = oct0; o < O; ++o) {
         const int oi = o - oct0;
         const int ww = c->ow[oi], hh = c->oh[oi], pp = c->op[oi];
+        da.oct[oi].w = ww;
+        da.oct[oi].h = hh;
+        da.oct[oi].p = pp;
+        da.oct[oi].qcap = c->qcap[oi];
+        da.oct[oi].blur_off = c->blur_off[oi];
+        da.oct[oi].dog_off = c->dog_off[oi];
+        da.oct[oi].queue_off = c->queue_off[oi];
+        da.band0[oi + 1] = da.band0[oi] + idivup(hh, 32);
+        da.dense0[oi + 1] = da.dense0[oi] + idivup(ww, 256) * idivup(hh, 32);
         if (o == oct0)
             r = hl_pyramid(imgs, ww, hh, pitch, img_stride, 0, A + c->blur_off[oi], AS,
-                           A + c->dog_off, AS, ww, pp, hh, S, nimg, &g_taps, stream);
+                           A + c->dog_off[oi], AS, ww, pp, hh, S, nimg, &g_taps, da.contrast,
+                           prefilter ? c->queue + c->queue_off[oi] : NULL, c->queue_stride, queued,
+                           COUNT_WORDS, c->qcap[oi], oi * S, stream);
         else /* cudaSiftH.cu:50-52: the next octave is the even pixels of blur plane S */
             r = hl_pyramid(A + c->blur_off[oi - 1] + (long)(S - 1) * c->op[oi - 1] * c->oh[oi - 1],
                            c->ow[oi - 1], c->oh[oi - 1], c->op[oi - 1], AS, 1, A + c->blur_off[oi],
-                           AS, A + c->dog_off, AS, ww, pp, hh, S, nimg, &g_taps, stream);
+                           AS, A + c->dog_off[oi], AS, ww, pp, hh, S, nimg, &g_taps, da.contrast,
+                           prefilter ? c->queue + c->queue_off[oi] : NULL, c->queue_stride, queued,
+                           COUNT_WORDS, c->qcap[oi], oi * S, stream);
         if (r) return fail_hl(r, "pyramid pass");
-        r = hl_detect(A + c->dog_off, AS, A + c->blur_off[oi], AS, ww, pp, hh, S, g_params.r_thresh,
-                      g_params.extrema_thresh, c->cand, c->cand_stride, c->counts, HL_MAX_GROUPS,
-                      oi * S, cap, nimg, stream);
-        if (r) return fail_hl(r, "detection");
     }
+    /* detection, once for all octaves: the pixels whose centre value the reference
+     * reads through an aliased cell join the queues, the queues are verified, and
+     * (only where a queue overflowed) a dense pass redoes the group */
+    if (prefilter) {
+        r = hl_alias_prefilter(A, AS, c->queue, c->queue_stride, queued, COUNT_WORDS, &da, nimg, stream);
+        if (r) return fail_hl(r, "aliased-row pre-filter");
+        r = hl_verify(A, AS, c->queue, c->queue_stride, queued, COUNT_WORDS, c->cand, c->cand_stride,
+                      c->counts, COUNT_WORDS, &da, nimg, stream);
+        if (r) return fail_hl(r, "candidate verification");
+    }
+    r = hl_detect(A, AS, c->cand, c->cand_stride, c->counts, COUNT_WORDS, prefilter ? queued : NULL,
+                  COUNT_WORDS, &da, nimg, stream);
+    if (r) return fail_hl(r, "dense detection");
     hl_keypoint_args ka;
     memset(&ka, 0, sizeof ka);
     ka.n_scales = S;
@@ -344,10 +399,10 @@ static int enqueue_extract(slot_ctx *c, SiftPoint *pts, unsigned char *meta, con
     memcpy(ka.desc_wnd, g_desc, sizeof g_desc);
     memcpy(ka.cos32, g_cos32, sizeof g_cos32);
     memcpy(ka.sin32, g_sin32, sizeof g_sin32);
-    r = hl_keypoints(pts, cap, meta, A, AS, c->cand, c->cand_stride, c->counts, HL_MAX_GROUPS,
+    r = hl_keypoints(pts, cap, meta, A, AS, c->cand, c->cand_stride, c->counts, COUNT_WORDS,
                      base_count, &ka, nimg, stream);
     if (r) return fail_hl(r, "keypoint kernel");
-    r = hl_finalize_counts(base_count, c->counts, HL_MAX_GROUPS, ka.n_groups, cap, nimg, stream);
+    r = hl_finalize_counts(base_count, c->counts, COUNT_WORDS, ka.n_groups, cap, nimg, stream);
     if (r) return fail_hl(r, "count update");
     c->last_stream = stream;
     return 0;

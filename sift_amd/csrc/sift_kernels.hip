@@ -251,15 +251,31 @@ __global__ __launch_bounds__(64) void col_blur_dog_kernel(
 // ---------------------------------------------------------------------------
 constexpr int FZ_PF = 4;
 constexpr int FZ_STAGE = 88; // floats staged per row
+constexpr int PQ_CAP = 512;  // contrast candidates one wave can hold per scale and strip
+
+// launch geometry of the reference's detector (cudaSiftH.cu:64-89): blocks of
+// 96x32 pixels in three 32-wide tiles, shared-memory tiles of 101x34 floats
+// (98 columns written) spaced 3168 floats apart
+constexpr int XT_DATAX = 96;
+constexpr int XT_BDIM = 32;
+constexpr int XT_SDIMX = 101;
+constexpr int XT_WRITTEN = 98;
+constexpr int XT_PLANE_OFF = 3168;
 
 template <int S, int SRC_MODE>
 __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     const float *__restrict__ src, int src_w, int src_h, int src_pitch, long src_stride,
     float *__restrict__ blur, long blur_stride, float *__restrict__ dog, long dog_stride, int w,
-    int p, int h, int rows, hl_taps taps)
+    int p, int h, int rows, hl_taps taps, float contrast, unsigned *__restrict__ queue,
+    long queue_stride, unsigned *__restrict__ qcount, long qcount_stride, int qcap, int group0)
 {
     constexpr int NP = S + 3;
     __shared__ float lds[2][128];
+    // contrast candidates of this strip: pixels whose centre-plane DoG exceeds
+    // the detector's threshold (cudaSiftD.cu:293), kept per scale in LDS and
+    // flushed to the global queue once, after the last row
+    __shared__ unsigned lq[S][PQ_CAP];
+    __shared__ unsigned lq_n[S];
     const int lane = threadIdx.x;
     const int x0 = blockIdx.x * 64;
     const int y0 = blockIdx.y * rows;
@@ -284,6 +300,15 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     const int out_lane = (x0 + lane) * 4;         // this lane's column
     unsigned out_row = (unsigned)y0 * p * 4u;     // the next completed output row
     const unsigned plane_b = (unsigned)plane * 4u;
+    // detector pre-filter: columns the reference can accept at all
+    // (cudaSiftD.cu:289: 8 < x < w-8; the middle tile of a 96-wide block never fires)
+    const bool pre = queue != nullptr;
+    const int xq = x0 + lane;
+    const int xq_tile = (xq % XT_DATAX) / XT_BDIM;
+    const bool pre_lane = xq > 8 && xq < w - 8 && xq_tile != 1;
+    const bool pre_lane0 = pre_lane && xq_tile == 0; // rows with y mod 32 = 30: see alias_prefilter_kernel
+    int yo_next = y0; // image row of the next completed output row
+    if (lane < S) lq_n[lane] = 0;
 
     // ---- source fetch of one row into registers ----
     // mode 0: lane j < 22 holds staged floats 4j..4j+3
@@ -402,6 +427,22 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b[i] - b[i + 1]), dg_rs, out_lane,
                                                               (int)(out_row + i * plane_b), 0);
                     out_row += (unsigned)p * 4u;
+                    // detector pre-filter: queue the pixels that pass the contrast test
+                    // (rare).  Pixels whose centre cell the reference reads through an
+                    // aliased shared-memory cell (y mod 32 = 31, and the right tile at
+                    // y mod 32 = 30) are left to alias_prefilter_kernel.  No global memory
+                    // is touched here, so the counted waits of the row loop stay exact.
+                    const int yo = yo_next++;
+                    if (pre && yo > 8 && yo < h - 8 && (yo & 31) < 31) { // wave-uniform
+                        const bool lane_pre = (yo & 31) == 30 ? pre_lane0 : pre_lane;
+#pragma unroll
+                        for (int i = 0; i < S; ++i) {
+                            if (lane_pre && fabsf(b[i + 1] - b[i + 2]) > contrast) {
+                                const unsigned slot = atomicAdd(&lq_n[i], 1u);
+                                if (slot < PQ_CAP) lq[i][slot] = (unsigned)xq | ((unsigned)yo << 16);
+                            }
+                        }
+                    }
                 }
             }
         });
@@ -410,6 +451,25 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     int rb = COL_RING;
     for (; rb + COL_RING <= nin; rb += COL_RING) chunk(std::false_type{}, rb);
     if (rb < nin) chunk(std::true_type{}, rb);
+
+    if (pre) { // flush the strip's candidates: one global atomic per scale
+        __syncthreads();
+        queue += z * queue_stride;
+        qcount += z * qcount_stride;
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const unsigned n = lq_n[i];
+            if (n == 0) continue;
+            unsigned base = 0;
+            // a strip that overflowed its LDS list poisons the count: the dense
+            // kernel then redoes this (image, scale) from the DoG planes
+            if (lane == 0) base = atomicAdd(&qcount[group0 + i], n > PQ_CAP ? (unsigned)qcap + 1u : n);
+            base = __shfl(base, 0);
+            if (n <= PQ_CAP)
+                for (unsigned e = lane; e < n; e += 64)
+                    if (base + e < (unsigned)qcap) queue[(long)i * qcap + base + e] = lq[i][e];
+        }
+    }
 }
 
 
@@ -420,11 +480,6 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
 // constants restate that geometry so the rule can be evaluated per pixel from
 // global memory under any tiling.
 // ---------------------------------------------------------------------------
-constexpr int XT_DATAX = 96;
-constexpr int XT_BDIM = 32;
-constexpr int XT_SDIMX = 101;
-constexpr int XT_WRITTEN = 98;
-constexpr int XT_PLANE_OFF = 3168;
 
 __device__ __forceinline__ float zpad(const float *pl, int w, int p, int h, int x, int y)
 {
@@ -485,118 +540,257 @@ __device__ int pixel_rank(const float *d3, long plane, int w, int p, int h, int 
     return r;
 }
 
-constexpr int DET_ROWS = 8; // image rows per wave
+// Full acceptance test of one contrast candidate (cudaSiftD.cu:271-293 after the
+// contrast clause): rank 9 with the carry of the reference's tile loop, then
+// the edge test on a Hessian of blur plane i+1 (hessianKernel, cudaSiftD.cu:405-419).
+__device__ bool accept_candidate(const float *d3, const float *blur_i, long plane, int w, int p,
+                                 int h, float edge_limit, int x, int y)
+{
+    int r = pixel_rank(d3, plane, w, p, h, x, y);
+    if ((x % XT_DATAX) >= 2 * XT_BDIM) { // the rank is carried over from the two tiles to the left
+        r += pixel_rank(d3, plane, w, p, h, x - 64, y);
+        r += pixel_rank(d3, plane, w, p, h, x - 32, y);
+    }
+    if (r != 9) return false;
+    const float *b = blur_i + x + (long)p * y;
+    const float c = b[0];
+    float Dxx = -2.f * c;
+    Dxx += b[-1];
+    Dxx += b[1];
+    float Dyy = -2.f * c;
+    Dyy += b[-p];
+    Dyy += b[p];
+    float Dxy = c;
+    Dxy += b[-p - 1];
+    Dxy -= b[-1];
+    Dxy -= b[-p];
+    const float trace = Dxx + Dyy;
+    const float det = Dxx * Dyy + Dxy * Dxy; // PLUS, and no contraction (cudaSiftD.cu:288)
+    return (trace * trace) / det < edge_limit;
+}
 
-// One wave per 256-pixel wide, DET_ROWS tall block of pixels, four pixels per
-// lane and row (one 16-byte load per centre plane and row, all issued before
-// the first use).  The contrast test |DoG| > threshold runs first because it
-// rejects almost every pixel from data already in registers.  Survivors go
-// through a per-wave LDS queue so that a cluster of them (they come in
-// clusters) is spread over all 64 lanes before the 27- or 81-cell rank and
-// the edge test are evaluated.  Accepted pixels are appended with one atomic
-// per wave (ballot + prefix count).
+// wave-aggregated append: one global atomic per wave (ballot + prefix count)
+__device__ __forceinline__ void append_hits(bool hit, unsigned xy, int lane, unsigned *count,
+                                            unsigned *list, int cap)
+{
+    const unsigned long long m = __ballot(hit);
+    if (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(count, (unsigned)__popcll(m));
+        base = __shfl(base, leader);
+        const unsigned idx = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (hit && idx < (unsigned)cap) list[idx] = xy;
+    }
+}
+
+constexpr int DET_ROWS = 8; // image rows per wave of the dense detector
+
+// The three detection kernels work on all octaves of a launch set at once:
+// blockIdx.y enumerates work units, the octave table says where each octave's
+// units start and where its planes, queues and sizes are.
+__device__ __forceinline__ int find_octave(const int *unit0, int n_oct, int unit)
+{
+    int o = 0;
+    while (o + 1 < n_oct && unit >= unit0[o + 1]) ++o;
+    return o;
+}
+
+// Pre-filter for the rows pyramid_kernel leaves out.  In the reference the
+// centre value of a pixel with y mod 32 = 30 or 31 is read through a
+// shared-memory cell that the next DoG plane's tile has overwritten
+// (cudaSiftD.cu:239-261), i.e. it is DoG_{i+2} at a shifted position:
+//   y mod 32 = 30, x mod 96 >= 36:  DoG_{i+2}[x-37, y-31]
+//   y mod 32 = 31, x mod 96 <= 32:  DoG_{i+2}[x+64, y-32]
+//   y mod 32 = 31, x mod 96 >= 36:  DoG_{i+2}[x-37, y-31]
+// (elsewhere the pixel's own value, which pyramid_kernel has tested).  Seen
+// from the source side: rows yA = 32b+31 and yC = 32b+32 of plane i+2 decide
+// the contrast test of pixels 31 or 32 rows below.  One wave reads those two
+// rows for 256 columns and queues the target pixels that pass.
 template <int S>
-__global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ dog, long dog_stride,
-                                                     const float *__restrict__ blur,
-                                                     long blur_stride, int w, int p, int h,
-                                                     float edge_limit, float contrast,
+__global__ __launch_bounds__(256) void alias_prefilter_kernel(const float *__restrict__ arena,
+                                                              long arena_stride, unsigned *queue,
+                                                              long queue_stride, unsigned *qcount,
+                                                              long qcount_stride, hl_detect_args a)
+{
+    const int lane = threadIdx.x & 63;
+    const int unit = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (unit >= a.band0[a.n_oct]) return; // whole wave; no barrier in this kernel
+    const int oi = find_octave(a.band0, a.n_oct, unit);
+    const hl_octave oc = a.oct[oi];
+    const int w = oc.w, h = oc.h, p = oc.p;
+    const int xs4 = blockIdx.x * 256 + 4 * lane;
+    if (blockIdx.x * 256 >= w) return; // wave-uniform
+    const int yA = (unit - a.band0[oi]) * 32 + 31, yC = yA + 1;
+    const int z = blockIdx.z;
+    const long plane = (long)p * h;
+    const float *dog = arena + z * arena_stride + oc.dog_off;
+    queue += z * queue_stride + oc.queue_off;
+    qcount += z * qcount_stride + oi * S;
+    const bool in_x = xs4 < w;
+
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        const float *src = dog + (i + 2) * plane;
+        float va[4] = {0.f, 0.f, 0.f, 0.f}, vc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (in_x && yA < h) {
+            const float4 t = *reinterpret_cast<const float4 *>(src + xs4 + (long)p * yA);
+            va[0] = t.x, va[1] = t.y, va[2] = t.z, va[3] = t.w;
+        }
+        if (in_x && yC < h) {
+            const float4 t = *reinterpret_cast<const float4 *>(src + xs4 + (long)p * yC);
+            vc[0] = t.x, vc[1] = t.y, vc[2] = t.z, vc[3] = t.w;
+        }
+        // up to three targets per source pixel: (a) and (b) from row yA, (c) from row yC
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int xs = xs4 + q;
+                const float v = t == 2 ? vc[q] : va[q];
+                const int xt = t == 1 ? xs - 64 : xs + 37;
+                const int yt = t == 0 ? yA + 31 : (t == 1 ? yA + 32 : yC + 31);
+                const int xm = xt % XT_DATAX;
+                const bool col_ok = t == 1 ? (xs >= 64 && xm < XT_BDIM) : (xm >= 2 * XT_BDIM);
+                const bool hit = xs < w && col_ok && xt > 8 && xt < w - 8 && yt > 8 && yt < h - 8 &&
+                                 fabsf(v) > a.contrast;
+                append_hits(hit, (unsigned)xt | ((unsigned)yt << 16), lane, &qcount[i],
+                            queue + (long)i * oc.qcap, oc.qcap);
+            }
+        }
+    }
+}
+
+// Sparse detector: consumes the contrast candidates queued by pyramid_kernel
+// and alias_prefilter_kernel.  blockIdx.y = (octave, scale) group.
+template <int S>
+__global__ __launch_bounds__(256) void verify_kernel(const float *__restrict__ arena, long arena_stride,
+                                                     const unsigned *queue, long queue_stride,
+                                                     const unsigned *qcount, long qcount_stride,
                                                      unsigned *cand, long cand_stride,
                                                      unsigned *counts, long counts_stride,
-                                                     int group0, int cap)
+                                                     hl_detect_args a)
+{
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.y, z = blockIdx.z;
+    const int oi = g / S, i = g - oi * S;
+    const hl_octave oc = a.oct[oi];
+    const unsigned n = qcount[z * qcount_stride + g];
+    if (n == 0 || n > (unsigned)oc.qcap) return; // overflow: the dense kernel takes this group
+    const long plane = (long)oc.p * oc.h;
+    const float *d3 = arena + z * arena_stride + oc.dog_off + i * plane;
+    const float *bi = arena + z * arena_stride + oc.blur_off + i * plane;
+    queue += z * queue_stride + oc.queue_off + (long)i * oc.qcap;
+    cand += z * cand_stride + (long)g * a.cap;
+    counts += z * counts_stride + g;
+    const unsigned step = gridDim.x * 256;
+    for (unsigned e0 = blockIdx.x * 256; e0 < n; e0 += step) { // block-uniform trip count
+        const unsigned e = e0 + threadIdx.x;
+        bool hit = false;
+        unsigned xy = 0;
+        if (e < n) {
+            xy = queue[e];
+            hit = accept_candidate(d3, bi, plane, oc.w, oc.p, oc.h, a.edge_limit, (int)(xy & 0xffffu),
+                                   (int)(xy >> 16));
+        }
+        append_hits(hit, xy, lane, counts, cand, a.cap);
+    }
+}
+
+// Dense detector.  One wave per 256-pixel wide, 8-row tall block of pixels,
+// four pixels per lane and row (one 16-byte load per centre plane and row, all
+// issued before the first use).  The contrast test runs first; survivors go
+// through a per-wave LDS queue so that a cluster of them is spread over all 64
+// lanes before the rank and edge tests.  With `gate` set a group is processed
+// only if its queue counter overflowed (gate[group] > qcap): the fall-back
+// behind the pre-filters.  With gate NULL it is the whole detector.
+template <int S>
+__global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ arena, long arena_stride,
+                                                     unsigned *cand, long cand_stride,
+                                                     unsigned *counts, long counts_stride,
+                                                     const unsigned *gate, long gate_stride,
+                                                     hl_detect_args a)
 {
     __shared__ unsigned q_xy[4][DET_ROWS * 256];
     __shared__ unsigned q_n[4];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    const int x4 = blockIdx.x * 256 + 4 * lane;
-    const int y0 = (blockIdx.y * 4 + wv) * DET_ROWS;
     const int z = blockIdx.z;
-    const long plane = (long)p * h;
-    dog += z * dog_stride;
-    blur += z * blur_stride;
     cand += z * cand_stride;
     counts += z * counts_stride;
-    // 96 and 32 are multiples of 4, so the four pixels of a lane share a tile;
-    // a pixel in the middle tile can never reach rank 9
-    const int tile = (x4 % XT_DATAX) / XT_BDIM;
-    const bool lane_ok = x4 < w && tile != 1;
+    if (gate) { // nothing to do for this image unless one of its queues overflowed
+        gate += z * gate_stride;
+        bool any = false;
+        for (int g = 0; g < a.n_oct * S; ++g) any = any || gate[g] > (unsigned)a.oct[g / S].qcap;
+        if (!any) return; // block-uniform
+    }
+    // dense0[] counts blocks of 256 x 32 pixels, octave after octave, row-major
+    for (int unit = blockIdx.x; unit < a.dense0[a.n_oct]; unit += gridDim.x) {
+        const int oi = find_octave(a.dense0, a.n_oct, unit);
+        const hl_octave oc = a.oct[oi];
+        const int w = oc.w, h = oc.h, p = oc.p;
+        const int xblocks = (w + 255) / 256;
+        const int u = unit - a.dense0[oi];
+        const int x4 = (u % xblocks) * 256 + 4 * lane;
+        const int y0 = ((u / xblocks) * 4 + wv) * DET_ROWS;
+        const long plane = (long)p * h;
+        const float *dog = arena + z * arena_stride + oc.dog_off;
+        const float *blur = arena + z * arena_stride + oc.blur_off;
+        // 96 and 32 are multiples of 4, so the four pixels of a lane share a tile;
+        // a pixel in the middle tile can never reach rank 9
+        const int tile = (x4 % XT_DATAX) / XT_BDIM;
+        const bool lane_ok = x4 < w && tile != 1;
 
 #pragma unroll
-    for (int i = 0; i < S; ++i) {
-        const float *d3 = dog + i * plane;
-        if (lane == 0) q_n[wv] = 0;
-        float v[DET_ROWS][4];
+        for (int i = 0; i < S; ++i) {
+            const int g = oi * S + i;
+            if (gate && gate[g] <= (unsigned)oc.qcap) continue; // block-uniform
+            const float *d3 = dog + i * plane;
+            if (lane == 0) q_n[wv] = 0;
+            float v[DET_ROWS][4];
 #pragma unroll
-        for (int r = 0; r < DET_ROWS; ++r) {
-            const int y = y0 + r;
-            const bool ok = lane_ok && y > 8 && y < h - 8; // cudaSiftD.cu:289-290
-            if ((y & 31) < 30) { // wave-uniform
-                const float4 t = *reinterpret_cast<const float4 *>(d3 + plane + (ok ? x4 + (long)p * y : 0));
-                v[r][0] = t.x;
-                v[r][1] = t.y;
-                v[r][2] = t.z;
-                v[r][3] = t.w;
-            } else { // the centre value itself is read through an aliased cell
+            for (int r = 0; r < DET_ROWS; ++r) {
+                const int y = y0 + r;
+                const bool ok = lane_ok && y > 8 && y < h - 8; // cudaSiftD.cu:289-290
+                if ((y & 31) < 30) { // wave-uniform
+                    const float4 t = *reinterpret_cast<const float4 *>(d3 + plane + (ok ? x4 + (long)p * y : 0));
+                    v[r][0] = t.x;
+                    v[r][1] = t.y;
+                    v[r][2] = t.z;
+                    v[r][3] = t.w;
+                } else { // the centre value itself is read through an aliased cell
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        v[r][q] = center_value(d3, plane, w, p, h, ok ? min(x4 + q, w - 1) : 0, ok ? y : 0);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < DET_ROWS; ++r) {
+                const int y = y0 + r;
+                const bool ok = lane_ok && y > 8 && y < h - 8;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    v[r][q] = center_value(d3, plane, w, p, h, ok ? min(x4 + q, w - 1) : 0, ok ? y : 0);
+                    if (ok && x4 + q > 8 && x4 + q < w - 8 && fabsf(v[r][q]) > a.contrast) {
+                        const unsigned slot = atomicAdd(&q_n[wv], 1u);
+                        q_xy[wv][slot] = (unsigned)(x4 + q) | ((unsigned)y << 16);
+                    }
             }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < DET_ROWS; ++r) {
-            const int y = y0 + r;
-            const bool ok = lane_ok && y > 8 && y < h - 8;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (ok && x4 + q > 8 && x4 + q < w - 8 && fabsf(v[r][q]) > contrast) {
-                    const unsigned slot = atomicAdd(&q_n[wv], 1u);
-                    q_xy[wv][slot] = (unsigned)(x4 + q) | ((unsigned)y << 16);
+            __syncthreads();
+            const unsigned nq = q_n[wv];
+            for (unsigned e0 = 0; e0 < nq; e0 += 64) { // wave-uniform trip count
+                const unsigned e = e0 + lane;
+                bool hit = false;
+                unsigned xy = 0;
+                if (e < nq) {
+                    xy = q_xy[wv][e];
+                    hit = accept_candidate(d3, blur + i * plane, plane, w, p, h, a.edge_limit,
+                                           (int)(xy & 0xffffu), (int)(xy >> 16));
                 }
-        }
-        __syncthreads();
-        const unsigned nq = q_n[wv];
-        for (unsigned e0 = 0; e0 < nq; e0 += 64) { // wave-uniform trip count
-            const unsigned e = e0 + lane;
-            bool hit = false;
-            unsigned xy = 0;
-            if (e < nq) {
-                xy = q_xy[wv][e];
-                const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
-                int r = pixel_rank(d3, plane, w, p, h, x, y);
-                if ((x % XT_DATAX) >= 2 * XT_BDIM) { // the rank is carried over from the two tiles to the left
-                    r += pixel_rank(d3, plane, w, p, h, x - 64, y);
-                    r += pixel_rank(d3, plane, w, p, h, x - 32, y);
-                }
-                if (r == 9) {
-                    const float *b = blur + i * plane + x + (long)p * y; // blur plane i+1
-                    const float c = b[0];
-                    float Dxx = -2.f * c;
-                    Dxx += b[-1];
-                    Dxx += b[1];
-                    float Dyy = -2.f * c;
-                    Dyy += b[-p];
-                    Dyy += b[p];
-                    float Dxy = c;
-                    Dxy += b[-p - 1];
-                    Dxy -= b[-1];
-                    Dxy -= b[-p];
-                    const float trace = Dxx + Dyy;
-                    const float det = Dxx * Dyy + Dxy * Dxy; // PLUS, and no contraction (cudaSiftD.cu:288)
-                    hit = (trace * trace) / det < edge_limit;
-                }
+                append_hits(hit, xy, lane, &counts[g], cand + (long)g * a.cap, a.cap);
             }
-            const unsigned long long m = __ballot(hit);
-            if (m) {
-                const int leader = __ffsll((long long)m) - 1;
-                unsigned base = 0;
-                if (lane == leader) base = atomicAdd(&counts[group0 + i], (unsigned)__popcll(m));
-                base = __shfl(base, leader);
-                const unsigned idx = base + __popcll(m & ((1ull << lane) - 1ull));
-                if (hit && idx < (unsigned)cap) cand[(long)(group0 + i) * cap + idx] = xy;
-            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 
@@ -652,13 +846,17 @@ __device__ float det_atan2f(float yf, float xf)
     return (float)r;
 }
 
+__device__ __forceinline__ void grad_from(float up, float down, float left, float right, float &mag,
+                                          float &dir);
 __device__ __forceinline__ void grad_at(const float *src, int w, int p, int h, int x, int y,
                                         float &mag, float &dir)
 {
-    const float up = zpad(src, w, p, h, x, y - 1);
-    const float down = zpad(src, w, p, h, x, y + 1);
-    const float left = zpad(src, w, p, h, x - 1, y);
-    const float right = zpad(src, w, p, h, x + 1, y);
+    grad_from(zpad(src, w, p, h, x, y - 1), zpad(src, w, p, h, x, y + 1), zpad(src, w, p, h, x - 1, y),
+              zpad(src, w, p, h, x + 1, y), mag, dir);
+}
+__device__ __forceinline__ void grad_from(float up, float down, float left, float right, float &mag,
+                                          float &dir)
+{
     const float dx = right - left;
     const float dy = down - up;
     mag = sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy))); // correctly rounded (the _rn intrinsic is the fast approximation)
@@ -727,14 +925,40 @@ __global__ __launch_bounds__(64) void keypoint_kernel(
         const float *bl = arena + oc.blur_off + (long)si * p * h; // blur plane si+1
 
         __syncthreads(); // previous keypoint's readers are done with the LDS arrays
-        for (int e = lane; e < REG * REG; e += 64) {
-            const int ry = e / REG, rx = e - ry * REG;
-            const int px = min(max(x - 11 + rx, 0), w - 1);
-            const int py = min(max(y - 11 + ry, 0), h - 1);
-            float m, d;
-            grad_at(bl, w, p, h, px, py, m, d);
-            s_mag[e] = m;
-            s_dir[e] = d;
+        {
+            // all 36 neighbour loads of the lane are issued before the first is used:
+            // one memory round trip per keypoint instead of nine
+            constexpr int ROUNDS = (REG * REG + 63) / 64;
+            float nb[ROUNDS][4];
+#pragma unroll
+            for (int q = 0; q < ROUNDS; ++q) {
+                const int e = min(lane + 64 * q, REG * REG - 1);
+                const int ry = e / REG, rx = e - ry * REG;
+                const int px = min(max(x - 11 + rx, 0), w - 1);
+                const int py = min(max(y - 11 + ry, 0), h - 1);
+                const float *c = bl + px + (long)p * py;
+                // clamped addresses, values outside the image replaced by 0 afterwards
+                nb[q][0] = c[py > 0 ? -p : 0];
+                nb[q][1] = c[py < h - 1 ? p : 0];
+                nb[q][2] = c[px > 0 ? -1 : 0];
+                nb[q][3] = c[px < w - 1 ? 1 : 0];
+            }
+#pragma unroll
+            for (int q = 0; q < ROUNDS; ++q) {
+                const int e = lane + 64 * q;
+                const int ec = min(e, REG * REG - 1);
+                const int ry = ec / REG, rx = ec - ry * REG;
+                const int px = min(max(x - 11 + rx, 0), w - 1);
+                const int py = min(max(y - 11 + ry, 0), h - 1);
+                const float up = py > 0 ? nb[q][0] : 0.f, down = py < h - 1 ? nb[q][1] : 0.f;
+                const float left = px > 0 ? nb[q][2] : 0.f, right = px < w - 1 ? nb[q][3] : 0.f;
+                float m, d;
+                grad_from(up, down, left, right, m, d);
+                if (e < REG * REG) {
+                    s_mag[e] = m;
+                    s_dir[e] = d;
+                }
+            }
         }
         __syncthreads();
 
@@ -1117,7 +1341,9 @@ int hl_col_blur_dog(const float *tmp, long tmp_stride, float *blur, long blur_st
 
 int hl_pyramid(const float *src, int src_w, int src_h, int src_pitch, long src_stride, int subsample,
                float *blur, long blur_stride, float *dog, long dog_stride, int w, int p, int h,
-               int n_scales, int nimg, const hl_taps *taps, void *stream)
+               int n_scales, int nimg, const hl_taps *taps, float contrast, unsigned *queue,
+               long queue_stride, unsigned *qcount, long qcount_stride, int qcap, int group0,
+               void *stream)
 {
     if (w <= 0 || h <= 0 || nimg <= 0 || !src || !blur || !dog || src_pitch < src_w) return -1001;
     if (p < w || (p & 63)) return -1005; // all 64 lanes of a block store: the pitch must cover them
@@ -1126,6 +1352,7 @@ int hl_pyramid(const float *src, int src_w, int src_h, int src_pitch, long src_s
     // 32-bit byte offsets inside one image's source, blur and DoG planes
     if ((long)p * h * (n_scales + 2) * 4 > 0xffffffffL || (long)src_pitch * src_h * 4 > 0xffffffffL)
         return -1007;
+    if (queue && (!qcount || qcap < 1 || w > 65535 || h > 65535)) return -1008;
     int m = 6; // strip height 20*m - 18, as in hl_col_blur_dog
     while (m > 2 && (long)idivup(w, 64) * idivup(h, COL_RING * m - 2 * RADIUS) * nimg < 2048) --m;
     const int rows = COL_RING * m - 2 * RADIUS;
@@ -1134,7 +1361,8 @@ int hl_pyramid(const float *src, int src_w, int src_h, int src_pitch, long src_s
     ScopedTimer t(4, s);
 #define PYR_LAUNCH(SS, MD)                                                                         \
     hipLaunchKernelGGL((pyramid_kernel<SS, MD>), grid, block, 0, s, src, src_w, src_h, src_pitch,  \
-                       src_stride, blur, blur_stride, dog, dog_stride, w, p, h, rows, *taps)
+                       src_stride, blur, blur_stride, dog, dog_stride, w, p, h, rows, *taps,       \
+                       contrast, queue, queue_stride, qcount, qcount_stride, qcap, group0)
     if (n_scales == 2 && !subsample)
         PYR_LAUNCH(2, 0);
     else if (n_scales == 2)
@@ -1149,28 +1377,71 @@ int hl_pyramid(const float *src, int src_w, int src_h, int src_pitch, long src_s
     return launch_status();
 }
 
-int hl_detect(const float *dog, long dog_stride, const float *blur, long blur_stride, int w,
-              int p, int h, int n_scales, float r_thresh, float extrema_thresh, unsigned *cand,
-              long cand_stride, unsigned *counts, long counts_stride, int group0, int cap,
-              int nimg, void *stream)
+static int detect_args_ok(const hl_detect_args *a, int nimg)
 {
-    if (w <= 0 || h <= 0 || nimg <= 0 || p < w || (p & 3) || w > 65535 || h > 65535) return -1001;
-    if ((((size_t)dog) & 15) || (dog_stride & 3)) return -1004;
-    if (w < 18 || h < 18) return 0; // no pixel satisfies 8 < x < w-8
-    const float edge_limit = (r_thresh * r_thresh) / r_thresh; // cudaSiftD.cu:292
-    dim3 grid(idivup(w, 256), idivup(h, 4 * DET_ROWS), nimg), block(256);
+    if (nimg <= 0 || a->n_oct < 1 || a->n_oct > HL_MAX_OCT || a->cap < 1) return 0;
+    if (a->n_scales != 2 && a->n_scales != 3) return 0;
+    for (int o = 0; o < a->n_oct; ++o) {
+        const hl_octave *c = &a->oct[o];
+        if (c->w < 1 || c->h < 1 || c->p < c->w || (c->p & 3) || c->w > 65535 || c->h > 65535) return 0;
+        if ((c->dog_off & 3) || c->qcap < 1) return 0;
+    }
+    return 1;
+}
+
+int hl_alias_prefilter(const float *arena, long arena_stride, unsigned *queue, long queue_stride,
+                       unsigned *qcount, long qcount_stride, const hl_detect_args *a, int nimg,
+                       void *stream)
+{
+    if (!detect_args_ok(a, nimg) || (arena_stride & 3) || (((size_t)arena) & 15)) return -1001;
+    dim3 grid(idivup(a->oct[0].w, 256), idivup(a->band0[a->n_oct], 4), nimg), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    ScopedTimer t(6, s);
+    if (a->n_scales == 2)
+        hipLaunchKernelGGL((alias_prefilter_kernel<2>), grid, block, 0, s, arena, arena_stride, queue,
+                           queue_stride, qcount, qcount_stride, *a);
+    else
+        hipLaunchKernelGGL((alias_prefilter_kernel<3>), grid, block, 0, s, arena, arena_stride, queue,
+                           queue_stride, qcount, qcount_stride, *a);
+    return launch_status();
+}
+
+int hl_verify(const float *arena, long arena_stride, const unsigned *queue, long queue_stride,
+              const unsigned *qcount, long qcount_stride, unsigned *cand, long cand_stride,
+              unsigned *counts, long counts_stride, const hl_detect_args *a, int nimg, void *stream)
+{
+    if (!detect_args_ok(a, nimg)) return -1001;
+    dim3 grid(8, a->n_oct * a->n_scales, nimg), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    ScopedTimer t(5, s);
+    if (a->n_scales == 2)
+        hipLaunchKernelGGL((verify_kernel<2>), grid, block, 0, s, arena, arena_stride, queue,
+                           queue_stride, qcount, qcount_stride, cand, cand_stride, counts,
+                           counts_stride, *a);
+    else
+        hipLaunchKernelGGL((verify_kernel<3>), grid, block, 0, s, arena, arena_stride, queue,
+                           queue_stride, qcount, qcount_stride, cand, cand_stride, counts,
+                           counts_stride, *a);
+    return launch_status();
+}
+
+int hl_detect(const float *arena, long arena_stride, unsigned *cand, long cand_stride,
+              unsigned *counts, long counts_stride, const unsigned *gate, long gate_stride,
+              const hl_detect_args *a, int nimg, void *stream)
+{
+    if (!detect_args_ok(a, nimg) || (arena_stride & 3) || (((size_t)arena) & 15)) return -1001;
+    // with a gate the kernel normally has nothing to do: few blocks, each walking
+    // over the units; without one it is the whole detector and fills the chip
+    const int gx = gate ? 32 : (a->dense0[a->n_oct] < 4096 ? a->dense0[a->n_oct] : 4096);
+    dim3 grid(gx, 1, nimg), block(256);
     hipStream_t s = (hipStream_t)stream;
     ScopedTimer t(2, s);
-    if (n_scales == 2)
-        hipLaunchKernelGGL((detect_kernel<2>), grid, block, 0, s, dog, dog_stride, blur, blur_stride,
-                           w, p, h, edge_limit, extrema_thresh, cand, cand_stride, counts,
-                           counts_stride, group0, cap);
-    else if (n_scales == 3)
-        hipLaunchKernelGGL((detect_kernel<3>), grid, block, 0, s, dog, dog_stride, blur, blur_stride,
-                           w, p, h, edge_limit, extrema_thresh, cand, cand_stride, counts,
-                           counts_stride, group0, cap);
+    if (a->n_scales == 2)
+        hipLaunchKernelGGL((detect_kernel<2>), grid, block, 0, s, arena, arena_stride, cand, cand_stride,
+                           counts, counts_stride, gate, gate_stride, *a);
     else
-        return -1002;
+        hipLaunchKernelGGL((detect_kernel<3>), grid, block, 0, s, arena, arena_stride, cand, cand_stride,
+                           counts, counts_stride, gate, gate_stride, *a);
     return launch_status();
 }
 
@@ -1180,7 +1451,8 @@ int hl_keypoints(void *pts, long pts_stride_points, unsigned char *meta, const f
                  int nimg, void *stream)
 {
     if (nimg <= 0 || args->n_groups <= 0 || args->n_groups > HL_MAX_GROUPS) return -1001;
-    int gx = args->cap < 2048 ? args->cap : 2048;
+    // one wave per keypoint, grid-stride: the count is only known on the device
+    int gx = args->cap < 512 ? args->cap : 512;
     if (gx < 1) gx = 1;
     dim3 grid(gx, nimg), block(64);
     hipStream_t s = (hipStream_t)stream;

@@ -210,3 +210,21 @@ def test_bad_arguments_are_reported_not_fatal(sift):
     sift.initDeviceVariables()
     sift.extractSift(pts, d, 16, 16, 10, None, 0, 0)  # too small for any keypoint: fine, zero points
     assert sift.getPointCount(0) == 0
+
+
+@pytest.mark.parametrize("queue_cap", [0, 16, 300])
+def test_detection_paths_agree(sift, oracle_mod, queue_cap):
+    """Queue capacity 0 = dense detector only; tiny capacities force the overflow fall-back for
+    some (octave, scale) groups and not others.  All paths give the oracle's points."""
+    pr = _params(sift, oracle_mod, n_scales=2, n_octaves=4, max_points=20000)
+    w, h = 640, 480
+    img = sift.synth_image(w, h, seed=6, dense=True)
+    ref, meta, _ = oracle_mod.extract(pr, img, w)
+    assert (meta[:, 0] == 0).sum() > 100 > (meta[:, 0] == 1).sum() > 0
+    assert (ref["ypos"].astype(int) % 32 >= 30).sum() > 0, "covers the aliased-centre rows"
+    sift.lib().sift_set_queue_cap(queue_cap)
+    try:
+        got = _extract_gpu(sift, img, w)
+    finally:
+        sift.lib().sift_set_queue_cap(65536)
+    _assert_points_equal(oracle_mod, got, ref)
