@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="images per launch set (0 = library default)")
     ap.add_argument("--lanes", type=int, default=0, help="launch sets in flight (0 = library default)")
     ap.add_argument("--dense", action="store_true", help="high keypoint density images")
+    ap.add_argument("--queue-cap", type=int, default=-1,
+                    help="candidate queue entries per image and scale (0 = dense detector only; -1 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=48)
     args = ap.parse_args()
@@ -101,6 +103,8 @@ def main():
         sift_amd.lib().sift_set_batch_chunk(args.chunk)
     if args.lanes:
         sift_amd.lib().sift_set_batch_lanes(args.lanes)
+    if args.queue_cap >= 0:
+        sift_amd.lib().sift_set_queue_cap(args.queue_cap)
 
     threads = min(16, os.cpu_count() or 1)
     host = gen_images(args.batch, SEED0 + rank * args.batch, args.dense, threads)

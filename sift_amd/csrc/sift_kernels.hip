@@ -1353,8 +1353,16 @@ int hl_pyramid(const float *src, int src_w, int src_h, int src_pitch, long src_s
     if ((long)p * h * (n_scales + 2) * 4 > 0xffffffffL || (long)src_pitch * src_h * 4 > 0xffffffffL)
         return -1007;
     if (queue && (!qcount || qcap < 1 || w > 65535 || h > 65535)) return -1008;
-    int m = 6; // strip height 20*m - 18, as in hl_col_blur_dog
-    while (m > 2 && (long)idivup(w, 64) * idivup(h, COL_RING * m - 2 * RADIUS) * nimg < 2048) --m;
+    // strip height 20*m - 18: every strip recomputes an 18-row apron, so strips are as
+    // tall as the launch allows while still giving the chip a few waves per SIMD, and
+    // equal in height so that no strip is a short left-over
+    int m = 11;
+    while (m > 2 && (long)idivup(w, 64) * idivup(h, COL_RING * m - 2 * RADIUS) * nimg < 6144) --m;
+    {
+        const int n_strips = idivup(h, COL_RING * m - 2 * RADIUS);
+        const int m_even = idivup(idivup(h, n_strips) + 2 * RADIUS, COL_RING);
+        if (m_even >= 2 && m_even < m) m = m_even;
+    }
     const int rows = COL_RING * m - 2 * RADIUS;
     dim3 grid(idivup(w, 64), idivup(h, rows), nimg), block(64);
     hipStream_t s = (hipStream_t)stream;

@@ -81,6 +81,7 @@ int main()
         run<0>("v_fma_f32 sgpr tap", w, 16);
         run<1>("v_pk_fma_f32 sgpr pair", w, 8);
         run<2>("v_pk_fma_f32 vgpr", w, 8);
+        run<3>("v_pk_fma_f32 sgpr x splat", w, 8);
     }
     return 0;
 }
