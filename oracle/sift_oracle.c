@@ -478,15 +478,17 @@ int oracle_find_extrema_literal(const OracleParams *pr, const float *dog3, const
 /* ---- orientation (intent of OrientationKernel, cudaSiftD.cu:17-94) --------
  * 16x16 patch [x-7,x+8] x [y-7,y+8]; weight mag*g[tx]*g[ty]; 32 bins; argmax,
  * first maximum wins; orientation = 11.25*bin degrees.
- * Summation order (the reference leaves it to shared-memory atomics): each
- * bin is the sum over samples 0..127 (index ty*16+tx, ascending) plus the sum
- * over samples 128..255 (ascending). */
+ * Summation order (the reference leaves it to shared-memory atomics): the 256
+ * samples (index s = ty*16+tx) form 64 groups of four consecutive samples;
+ * within a group, samples of one bin are added in ascending order; a bin is
+ * then (partials of groups 0..31 added in ascending order) + (the same for
+ * groups 32..63). */
 float oracle_orientation(const float *grad2, int w, int p, int h, const float *g16, int x, int y,
                          float *hist32)
 {
     long gDim = (long)p * h;
-    float half[2][32];
-    memset(half, 0, sizeof(half));
+    static __thread float part[64][32];
+    memset(part, 0, sizeof(part));
     for (int ty = 0; ty < 16; ++ty)
         for (int tx = 0; tx < 16; ++tx) {
             long g = (x - 7 + tx) + (long)p * (y - 7 + ty);
@@ -496,11 +498,19 @@ float oracle_orientation(const float *grad2, int w, int p, int h, const float *g
             wgt = wgt * g16[ty];
             int b = oracle_assign_bin(d, 32);
             int s = ty * 16 + tx;
-            half[s >> 7][b] += wgt;
+            part[s >> 2][b] += wgt;
         }
     float hist[32];
-    for (int b = 0; b < 32; ++b)
-        hist[b] = half[0][b] + half[1][b];
+    for (int b = 0; b < 32; ++b) {
+        float half[2];
+        for (int hf = 0; hf < 2; ++hf) {
+            float a = 0.0f;
+            for (int L = 32 * hf; L < 32 * hf + 32; ++L)
+                a = a + part[L][b];
+            half[hf] = a;
+        }
+        hist[b] = half[0] + half[1];
+    }
     float best = hist[0];
     for (int b = 1; b < 32; ++b)
         best = fmaxf(best, hist[b]);
@@ -584,11 +594,16 @@ void oracle_descriptor(const float *grad2, int w, int p, int h, const float *dw,
     for (int cy = 0; cy < 4; ++cy)
         for (int cx = 0; cx < 4; ++cx)
             for (int b = 0; b < 8; ++b) {
+                /* rows of the cell are summed separately (ascending tx), then
+                 * combined as ((P0 + P1) + P2) + P3 */
                 float s = 0.0f;
-                for (int ty = 4 * cy; ty < 4 * cy + 4; ++ty)
+                for (int ty = 4 * cy; ty < 4 * cy + 4; ++ty) {
+                    float row = 0.0f;
                     for (int tx = 4 * cx; tx < 4 * cx + 4; ++tx)
                         if (bin[ty * 16 + tx] == b)
-                            s += wgt[ty * 16 + tx];
+                            row += wgt[ty * 16 + tx];
+                    s = (ty == 4 * cy) ? row : s + row;
+                }
                 hist[b + 8 * cx + 32 * cy] = s;
             }
     float S1 = hist_sum128(hist);

@@ -250,8 +250,9 @@ __global__ __launch_bounds__(64) void col_blur_dog_kernel(
 //             the fetch; the down-sampled base is never materialised)
 // ---------------------------------------------------------------------------
 constexpr int FZ_PF = 4;
+static_assert(20 % FZ_PF == 0, "the prefetch ring must divide the row chunk");
 constexpr int FZ_STAGE = 88; // floats staged per row
-constexpr int PQ_CAP = 512;  // contrast candidates one wave can hold per scale and strip
+constexpr int PQ_CAP = 1024; // contrast candidates one wave can hold per scale between flushes
 
 // launch geometry of the reference's detector (cudaSiftH.cu:64-89): blocks of
 // 96x32 pixels in three 32-wide tiles, shared-memory tiles of 101x34 floats
@@ -447,29 +448,42 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
             }
         });
     };
-    chunk(std::true_type{}, 0);
-    int rb = COL_RING;
-    for (; rb + COL_RING <= nin; rb += COL_RING) chunk(std::false_type{}, rb);
-    if (rb < nin) chunk(std::true_type{}, rb);
-
-    if (pre) { // flush the strip's candidates: one global atomic per scale
+    // Moves the strip's candidates so far to the global queue: one global atomic
+    // per scale.  A list that overflowed poisons the count: the dense kernel then
+    // redoes this (image, scale) from the DoG planes.
+    auto flush = [&]() __attribute__((always_inline)) {
         __syncthreads();
-        queue += z * queue_stride;
-        qcount += z * qcount_stride;
 #pragma unroll
         for (int i = 0; i < S; ++i) {
             const unsigned n = lq_n[i];
             if (n == 0) continue;
             unsigned base = 0;
-            // a strip that overflowed its LDS list poisons the count: the dense
-            // kernel then redoes this (image, scale) from the DoG planes
-            if (lane == 0) base = atomicAdd(&qcount[group0 + i], n > PQ_CAP ? (unsigned)qcap + 1u : n);
+            if (lane == 0) base = atomicAdd(&qcount[z * qcount_stride + group0 + i], n > PQ_CAP ? (unsigned)qcap + 1u : n);
             base = __shfl(base, 0);
             if (n <= PQ_CAP)
                 for (unsigned e = lane; e < n; e += 64)
-                    if (base + e < (unsigned)qcap) queue[(long)i * qcap + base + e] = lq[i][e];
+                    if (base + e < (unsigned)qcap) queue[z * queue_stride + (long)i * qcap + base + e] = lq[i][e];
         }
+        __syncthreads();
+        if (lane < S) lq_n[lane] = 0;
+    };
+    // a row adds at most 64 entries per scale, a chunk of 20 rows rarely more
+    // than a few: the lists are emptied between chunks once half full
+    auto flush_if_filling = [&]() __attribute__((always_inline)) {
+        if (!pre) return;
+        unsigned fill = 0;
+#pragma unroll
+        for (int i = 0; i < S; ++i) fill = max(fill, lq_n[i]);
+        if (__builtin_amdgcn_readfirstlane(fill) > PQ_CAP / 2) flush();
+    };
+    chunk(std::true_type{}, 0);
+    int rb = COL_RING;
+    for (; rb + COL_RING <= nin; rb += COL_RING) {
+        chunk(std::false_type{}, rb);
+        flush_if_filling();
     }
+    if (rb < nin) chunk(std::true_type{}, rb);
+    if (pre) flush();
 }
 
 
@@ -604,7 +618,7 @@ __device__ __forceinline__ int find_octave(const int *unit0, int n_oct, int unit
 //   y mod 32 = 31, x mod 96 <= 32:  DoG_{i+2}[x+64, y-32]
 //   y mod 32 = 31, x mod 96 >= 36:  DoG_{i+2}[x-37, y-31]
 // (elsewhere the pixel's own value, which pyramid_kernel has tested).  Seen
-// from the source side: rows yA = 32b+31 and yC = 32b+32 of plane i+2 decide
+// from the source side: rows yA = 32b-1 and yC = 32b of plane i+2 decide
 // the contrast test of pixels 31 or 32 rows below.  One wave reads those two
 // rows for 256 columns and queues the target pixels that pass.
 template <int S>
@@ -621,7 +635,7 @@ __global__ __launch_bounds__(256) void alias_prefilter_kernel(const float *__res
     const int w = oc.w, h = oc.h, p = oc.p;
     const int xs4 = blockIdx.x * 256 + 4 * lane;
     if (blockIdx.x * 256 >= w) return; // wave-uniform
-    const int yA = (unit - a.band0[oi]) * 32 + 31, yC = yA + 1;
+    const int yC = (unit - a.band0[oi]) * 32, yA = yC - 1; // row 0 is a source row too (targets at y = 31)
     const int z = blockIdx.z;
     const long plane = (long)p * h;
     const float *dog = arena + z * arena_stride + oc.dog_off;
@@ -633,7 +647,7 @@ __global__ __launch_bounds__(256) void alias_prefilter_kernel(const float *__res
     for (int i = 0; i < S; ++i) {
         const float *src = dog + (i + 2) * plane;
         float va[4] = {0.f, 0.f, 0.f, 0.f}, vc[4] = {0.f, 0.f, 0.f, 0.f};
-        if (in_x && yA < h) {
+        if (in_x && yA >= 0) {
             const float4 t = *reinterpret_cast<const float4 *>(src + xs4 + (long)p * yA);
             va[0] = t.x, va[1] = t.y, va[2] = t.z, va[3] = t.w;
         }
@@ -828,17 +842,17 @@ __device__ float det_atan2f(float yf, float xf)
     const double ax = fabs(x), ay = fabs(y);
     const double mx = ax > ay ? ax : ay;
     const double mn = ax > ay ? ay : ax;
-    double r;
-    if (mx == 0.0) {
-        r = 0.0;
-    } else {
+    // One polynomial evaluation serves both ranges: the argument and the
+    // constant term are selected first (0 + atan_small(a) is atan_small(a)
+    // exactly), so lanes that fall on different sides of the split do not
+    // make the wave run the series twice.
+    double r = 0.0;
+    if (mx != 0.0) {
         const double a = mn / mx;
-        if (a > 0.41421356237309503) {
-            const double t = (a - 1.0) / (a + 1.0);
-            r = 0.78539816339744831 + atan_small(t);
-        } else {
-            r = atan_small(a);
-        }
+        const bool upper = a > 0.41421356237309503;
+        const double t = upper ? (a - 1.0) / (a + 1.0) : a;
+        const double base = upper ? 0.78539816339744831 : 0.0;
+        r = base + atan_small(t);
     }
     if (ay > ax) r = 1.57079632679489662 - r;
     if (x < 0.0) r = 3.14159265358979323846 - r;
@@ -879,9 +893,25 @@ struct SiftPointD {
 constexpr int REG = 23; // gradient region [x-11, x+11]: covers the rotated 16x16 patch
 
 // One wave per keypoint.  Float sums whose order the reference leaves to
-// atomics are taken in one fixed order: an orientation bin is (sum over
-// samples 0..127 ascending) + (sum over samples 128..255 ascending); a
-// descriptor bin is the sum over its cell's 16 samples, rows then columns.
+// atomics are taken in one fixed order built from per-lane partial sums.  Lane
+// L owns the four samples (ty, 4*(L&3) .. 4*(L&3)+3) of row ty = L >> 2 and
+// adds those that fall into one bin in ascending tx.  An orientation bin is
+// (partials of lanes 0..31 added in ascending order) + (the same for lanes
+// 32..63); a descriptor bin is ((P0 + P1) + P2) + P3 over the four rows of its
+// cell.
+constexpr int OH_STRIDE = 33; // orientation partials: 64 lanes x 32 bins, padded against bank conflicts
+constexpr int DH_STRIDE = 9;  // descriptor partials: 64 lanes x 8 bins
+
+// the value lane-sequential accumulation leaves in each sample's bin: sample k
+// continues the running sum of the latest earlier sample with the same bin
+__device__ __forceinline__ void chain4(const int (&b)[4], const float (&w)[4], float (&o)[4])
+{
+    o[0] = w[0];
+    o[1] = __fadd_rn(b[1] == b[0] ? o[0] : 0.f, w[1]);
+    o[2] = __fadd_rn(b[2] == b[1] ? o[1] : (b[2] == b[0] ? o[0] : 0.f), w[2]);
+    o[3] = __fadd_rn(b[3] == b[2] ? o[2] : (b[3] == b[1] ? o[1] : (b[3] == b[0] ? o[0] : 0.f)), w[3]);
+}
+
 __global__ __launch_bounds__(64) void keypoint_kernel(
     SiftPointD *pts, long pts_stride, unsigned char *meta, const float *arena, long arena_stride,
     const unsigned *cand, long cand_stride, const unsigned *counts, long counts_stride,
@@ -889,8 +919,7 @@ __global__ __launch_bounds__(64) void keypoint_kernel(
 {
     __shared__ float s_mag[REG * REG + 3];
     __shared__ float s_dir[REG * REG + 3];
-    __shared__ float s_w[256];
-    __shared__ int s_b[256];
+    __shared__ __attribute__((aligned(16))) float s_part[64 * 36];
 
     const int lane = threadIdx.x;
     const int z = blockIdx.y;
@@ -963,23 +992,30 @@ __global__ __launch_bounds__(64) void keypoint_kernel(
         __syncthreads();
 
         // ---- orientation: 16x16 patch [x-7,x+8] x [y-7,y+8], 32 bins ----
+        const int ty = lane >> 2, tx0 = 4 * (lane & 3);
+        {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int s = lane + 64 * q;
-            const int tx = s & 15, ty = s >> 4;
-            const int e = (ty + 4) * REG + tx + 4;
-            float wgt = __fmul_rn(s_mag[e], a.wnd[si * 16 + tx]);
-            wgt = __fmul_rn(wgt, a.wnd[si * 16 + ty]);
-            s_w[s] = wgt;
-            s_b[s] = assign_bin(s_dir[e], 11.25f);
+            for (int q = 0; q < 9; ++q) reinterpret_cast<float4 *>(s_part)[lane + 64 * q] = float4{0.f, 0.f, 0.f, 0.f};
+            int ob[4];
+            float ow[4], oo[4];
+            const float wy = a.wnd[si * 16 + ty];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = (ty + 4) * REG + tx0 + k + 4;
+                ow[k] = __fmul_rn(__fmul_rn(s_mag[e], a.wnd[si * 16 + tx0 + k]), wy);
+                ob[k] = assign_bin(s_dir[e], 11.25f);
+            }
+            chain4(ob, ow, oo);
+            __syncthreads(); // the zeroes are in place
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s_part[lane * OH_STRIDE + ob[k]] = oo[k]; // in order: the last write of a bin wins
         }
         __syncthreads();
         float hsum = 0.f;
         {
-            const int b = lane & 31;
-            const int s0 = (lane >> 5) * 128;
-            for (int s = s0; s < s0 + 128; ++s)
-                if (s_b[s] == b) hsum = __fadd_rn(hsum, s_w[s]);
+            const float *col = s_part + (lane >> 5) * 32 * OH_STRIDE + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) hsum = __fadd_rn(hsum, col[i * OH_STRIDE]);
         }
         hsum = __fadd_rn(hsum, __shfl_down(hsum, 32));
         float mx = hsum;
@@ -995,34 +1031,44 @@ __global__ __launch_bounds__(64) void keypoint_kernel(
 
         // ---- descriptor: rotated 16x16 samples, bilinear, 4x4 cells x 8 bins ----
         const float cs = a.cos32[oidx], sn = a.sin32[oidx];
+        {
+            int db[4];
+            float dwt[4], dout[4];
+            const float dy = (float)ty - 7.5f;
+            const float wy = a.desc_wnd[ty];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int s = lane + 64 * q;
-            const int tx = s & 15, ty = s >> 4;
-            const float dx = (float)tx - 7.5f, dy = (float)ty - 7.5f;
-            const float u = __fadd_rn(__fmul_rn(dx, cs), __fmul_rn(dy, sn));
-            const float v = __fsub_rn(__fmul_rn(dy, cs), __fmul_rn(dx, sn));
-            const float px = __fadd_rn((float)x, u), py = __fadd_rn((float)y, v);
-            const float fx = floorf(px), fy = floorf(py);
-            const float ax = __fsub_rn(px, fx), ay = __fsub_rn(py, fy);
-            // region entry r holds the value of pixel clamp(x-11+r), so the
-            // clamp-to-edge addressing needs no further clamping here
-            const int rx = min(max((int)fx - (x - 11), 0), REG - 2);
-            const int ry = min(max((int)fy - (y - 11), 0), REG - 2);
-            const int e = ry * REG + rx;
-            float val[2];
+            for (int k = 0; k < 4; ++k) {
+                const int tx = tx0 + k;
+                const float dx = (float)tx - 7.5f;
+                const float u = __fadd_rn(__fmul_rn(dx, cs), __fmul_rn(dy, sn));
+                const float v = __fsub_rn(__fmul_rn(dy, cs), __fmul_rn(dx, sn));
+                const float px = __fadd_rn((float)x, u), py = __fadd_rn((float)y, v);
+                const float fx = floorf(px), fy = floorf(py);
+                const float ax = __fsub_rn(px, fx), ay = __fsub_rn(py, fy);
+                // region entry r holds the value of pixel clamp(x-11+r), so the
+                // clamp-to-edge addressing needs no further clamping here
+                const int rx = min(max((int)fx - (x - 11), 0), REG - 2);
+                const int ry = min(max((int)fy - (y - 11), 0), REG - 2);
+                const int e = ry * REG + rx;
+                float val[2];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const float *pl = c ? s_dir : s_mag;
-                const float v00 = pl[e], v10 = pl[e + 1], v01 = pl[e + REG], v11 = pl[e + REG + 1];
-                const float top = __builtin_fmaf(ax, __fsub_rn(v10, v00), v00);
-                const float bot = __builtin_fmaf(ax, __fsub_rn(v11, v01), v01);
-                val[c] = __builtin_fmaf(ay, __fsub_rn(bot, top), top);
+                for (int c = 0; c < 2; ++c) {
+                    const float *pl = c ? s_dir : s_mag;
+                    const float v00 = pl[e], v10 = pl[e + 1], v01 = pl[e + REG], v11 = pl[e + REG + 1];
+                    const float top = __builtin_fmaf(ax, __fsub_rn(v10, v00), v00);
+                    const float bot = __builtin_fmaf(ax, __fsub_rn(v11, v01), v01);
+                    val[c] = __builtin_fmaf(ay, __fsub_rn(bot, top), top);
+                }
+                dwt[k] = __fmul_rn(__fmul_rn(val[0], a.desc_wnd[tx]), wy);
+                db[k] = assign_bin(val[1], 45.f);
             }
-            float wgt = __fmul_rn(val[0], a.desc_wnd[tx]);
-            wgt = __fmul_rn(wgt, a.desc_wnd[ty]);
-            s_w[s] = wgt;
-            s_b[s] = assign_bin(val[1], 45.f);
+            chain4(db, dwt, dout);
+            // the orientation partials have been consumed (the ballot above joins the wave)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) reinterpret_cast<float4 *>(s_part)[lane + 64 * q] = float4{0.f, 0.f, 0.f, 0.f};
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s_part[lane * DH_STRIDE + db[k]] = dout[k];
         }
         __syncthreads();
         float hv[2];
@@ -1030,14 +1076,10 @@ __global__ __launch_bounds__(64) void keypoint_kernel(
         for (int q = 0; q < 2; ++q) {
             const int e = lane + 64 * q;
             const int cy = e >> 5, cx = (e >> 3) & 3, b = e & 7;
-            float sum = 0.f;
+            const float *row = s_part + ((16 * cy + cx) * DH_STRIDE + b); // lane (4*cy + r)*4 + cx
+            float sum = row[0];
 #pragma unroll
-            for (int ty = 0; ty < 4; ++ty)
-#pragma unroll
-                for (int tx = 0; tx < 4; ++tx) {
-                    const int s = (4 * cy + ty) * 16 + 4 * cx + tx;
-                    if (s_b[s] == b) sum = __fadd_rn(sum, s_w[s]);
-                }
+            for (int r = 1; r < 4; ++r) sum = __fadd_rn(sum, row[r * 4 * DH_STRIDE]);
             hv[q] = sum;
         }
         // L1 normalise, clamp at 0.2, L1 normalise (cudaSiftD.cu:186-200); the

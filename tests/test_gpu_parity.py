@@ -228,3 +228,40 @@ def test_detection_paths_agree(sift, oracle_mod, queue_cap):
     finally:
         sift.lib().sift_set_queue_cap(65536)
     _assert_points_equal(oracle_mod, got, ref)
+
+
+@pytest.mark.parametrize("thresh", [3.0, 0.5])
+def test_many_candidates_per_strip(sift, oracle_mod, thresh):
+    """A low contrast threshold on a tall image: every 64-column strip of the pyramid kernel
+    collects far more candidates than its in-LDS list holds between flushes (threshold 3) or
+    than one chunk of rows may add (threshold 0.5: the list overflows and the dense detector
+    takes the group over).  The result is still the oracle's."""
+    pr = _params(sift, oracle_mod, n_scales=2, n_octaves=3, max_points=60000, extrema_thresh=thresh)
+    w, h = 192, 1500
+    img = sift.synth_image(w, h, seed=77, dense=True)
+    ref, _, total = oracle_mod.extract(pr, img, w)
+    assert total == len(ref) > 1000
+    got = _extract_gpu(sift, img, w)
+    _assert_points_equal(oracle_mod, got, ref)
+
+
+def test_sparse_and_dense_detectors_agree_on_random_shapes(sift, oracle_mod):
+    """The queue-driven detector (contrast pre-filter in the pyramid kernel, aliased-row
+    pre-filter, verify) against the dense detector over random sizes, scales and contrast
+    thresholds.  The dense detector is the one the oracle comparisons above pin."""
+    rng = np.random.default_rng(5)
+    for case in range(16):
+        w, h = int(rng.integers(40, 700)), int(rng.integers(40, 700))
+        S = int(rng.integers(2, 4))
+        thr = float(rng.choice([1.0, 3.0, 10.0]))
+        sift.set_params(n_scales=S, n_octaves=4, max_points=60000, extrema_thresh=thr)
+        img = sift.synth_image(w, h, seed=300 + case, dense=True)
+        sift.lib().sift_set_queue_cap(0)
+        try:
+            dense = _extract_gpu(sift, img, w)
+        finally:
+            sift.lib().sift_set_queue_cap(65536)
+        sparse = _extract_gpu(sift, img, w)
+        assert len(dense) == len(sparse), (case, w, h, S, thr, len(dense), len(sparse))
+        assert oracle_mod.sort_points(dense).tobytes() == oracle_mod.sort_points(sparse).tobytes(), (case, w, h, S, thr)
+    assert len(dense) > 0

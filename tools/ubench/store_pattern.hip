@@ -1,0 +1,76 @@
+// Micro-benchmark: HBM write rate of the fused pyramid kernel's store pattern
+// (every wave writes one 256-byte row segment into each of NPL planes per row,
+// walking down a strip) against a flat 16-byte-per-lane streaming store, and
+// the same with a concurrent read stream of one plane.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+template <int NPL, bool READ>
+__global__ __launch_bounds__(64) void strips(float *out, const float *in, int p, int h, int rows, long img_stride)
+{
+    const int lane = threadIdx.x;
+    const int x = blockIdx.x * 64 + lane;
+    const int y0 = blockIdx.y * rows;
+    const int y1 = min(y0 + rows, h);
+    float *o = out + blockIdx.z * img_stride;
+    const float *s = in + blockIdx.z * (long)p * h;
+    const long plane = (long)p * h;
+    float v = (float)lane;
+    for (int y = y0; y < y1; ++y) {
+        if (READ) v += s[(long)y * p + x];
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) o[i * plane + (long)y * p + x] = v + i;
+    }
+}
+
+__global__ __launch_bounds__(256) void flat(float4 *out, long n)
+{
+    long i = blockIdx.x * 256L + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (; i < n; i += stride) out[i] = float4{1.f, 2.f, 3.f, (float)i};
+}
+
+int main()
+{
+    const int w = 1920, h = 1080, p = 1920, nimg = 64, NPL = 6;
+    const long plane = (long)p * h, img_stride = plane * NPL;
+    float *out, *in;
+    hipMalloc(&out, img_stride * nimg * 4);
+    hipMalloc(&in, plane * nimg * 4);
+    hipMemset(in, 0, plane * nimg * 4);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const double bytes = (double)img_stride * nimg * 4;
+    for (int rows : {102, 182}) {
+        for (int rd = 0; rd < 2; ++rd) {
+            dim3 grid(w / 64, (h + rows - 1) / rows, nimg);
+            float best = 1e9;
+            for (int it = 0; it < 4; ++it) {
+                hipEventRecord(e0, 0);
+                if (rd) hipLaunchKernelGGL((strips<NPL, true>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride);
+                else hipLaunchKernelGGL((strips<NPL, false>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride);
+                hipEventRecord(e1, 0);
+                hipEventSynchronize(e1);
+                float ms;
+                hipEventElapsedTime(&ms, e0, e1);
+                if (it && ms < best) best = ms;
+            }
+            printf("strip stores rows=%d read=%d: %.3f ms  write %.2f TB/s\n", rows, rd, best, bytes / best / 1e9);
+        }
+    }
+    {
+        float best = 1e9;
+        for (int it = 0; it < 4; ++it) {
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(flat, dim3(256 * 16), dim3(256), 0, 0, (float4 *)out, (long)(bytes / 16));
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (it && ms < best) best = ms;
+        }
+        printf("flat 16B/lane stores: %.3f ms  write %.2f TB/s\n", best, bytes / best / 1e9);
+    }
+    return 0;
+}
