@@ -236,10 +236,17 @@ __global__ __launch_bounds__(64) void col_blur_dog_kernel(
 //
 // Memory pipeline.  On gfx9-family hardware loads and stores retire through
 // one in-order counter, so a wave can only leave loads in flight across its
-// stores if the compiler can count both exactly.  The steady-state chunk of 20
-// rows is therefore straight-line code: every load and every store is issued
-// unconditionally (addresses are clamped, values are zeroed by selects, all 64
-// lanes store -- columns [w, pitch) of the destination planes are scratch).
+// stores if the compiler can count both exactly -- and its counts are static
+// per instruction, merged over every path that reaches it.  The whole strip is
+// therefore ONE loop over a straight-line chunk of 20 rows in which every row
+// issues the same two loads and S + (S+2) stores unconditionally: load
+// addresses are clamped and the values zeroed with masks; the stores of rows
+// that complete no output row of this strip (the first 18 input rows, and any
+// row past the strip's end in the last chunk) carry an out-of-range buffer
+// offset, which the hardware drops without memory traffic.  The first chunk is
+// peeled off in front of the loop, so the loop is entered in the same counter
+// state its back edge produces.  All 64 lanes store: columns [w, pitch) of the
+// destination planes are scratch.
 // Source rows are fetched FZ_PF rows ahead into registers; the LDS row buffer
 // has two slots so the write of row r+1 is issued a whole step before its
 // first read.
@@ -253,6 +260,7 @@ constexpr int FZ_PF = 4;
 static_assert(20 % FZ_PF == 0, "the prefetch ring must divide the row chunk");
 constexpr int FZ_STAGE = 88; // floats staged per row
 constexpr int PQ_CAP = 1024; // contrast candidates one wave can hold per scale between flushes
+constexpr unsigned FZ_DROP = 0xfffffff0u; // per-lane buffer offset past every plane: the store is dropped
 
 // launch geometry of the reference's detector (cudaSiftH.cu:64-89): blocks of
 // 96x32 pixels in three 32-wide tiles, shared-memory tiles of 101x34 floats
@@ -278,12 +286,27 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     __shared__ unsigned lq[S][PQ_CAP];
     __shared__ unsigned lq_n[S];
     const int lane = threadIdx.x;
-    const int x0 = blockIdx.x * 64;
-    const int y0 = blockIdx.y * rows;
+    // Workgroups are handed to the 8 XCDs round-robin, each XCD with its own
+    // L2.  The remap gives every XCD one contiguous run of (column, strip,
+    // image) tiles, so the waves that share source lines (neighbouring columns)
+    // fetch them through the same L2.  Bijective for any grid size.
+    int tile_x, tile_y, tile_z;
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y;
+        const unsigned nwg = gx * gy * gridDim.z;
+        const unsigned orig = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const unsigned q = nwg / 8, r = nwg % 8, xcd = orig % 8;
+        const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+        tile_x = (int)(t % gx);
+        tile_y = (int)((t / gx) % gy);
+        tile_z = (int)(t / (gx * gy));
+    }
+    const int x0 = tile_x * 64;
+    const int y0 = tile_y * rows;
     const int y1 = min(y0 + rows, h);
     const int nin = (y1 - y0) + 2 * RADIUS;
     const long plane = (long)p * h;
-    const int z = blockIdx.z;
+    const int z = tile_z;
     src += z * src_stride;
     // buffer descriptors (wave-uniform): 32-bit per-lane offsets in one VGPR and
     // per-row / per-plane offsets in scalar registers replace 64-bit per-lane
@@ -291,9 +314,9 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(src), 0, (int)(unsigned)min((long)src_pitch * src_h * 4, 0xffffffffL), 0x00020000);
     const __amdgpu_buffer_rsrc_t bl_rs = __builtin_amdgcn_make_buffer_rsrc(
-        blur + z * blur_stride, 0, (int)(unsigned)min(plane * S * 4, 0xffffffffL), 0x00020000);
+        blur + z * blur_stride, 0, (int)(unsigned)min(plane * S * 4, (long)FZ_DROP), 0x00020000);
     const __amdgpu_buffer_rsrc_t dg_rs = __builtin_amdgcn_make_buffer_rsrc(
-        dog + z * dog_stride, 0, (int)(unsigned)min(plane * (S + 2) * 4, 0xffffffffL), 0x00020000);
+        dog + z * dog_stride, 0, (int)(unsigned)min(plane * (S + 2) * 4, (long)FZ_DROP), 0x00020000);
     // destination of the next completed output row; advanced row by row (a
     // loop-carried pointer: offsets formed from the unrolled row index would be
     // hoisted out of the loop as dozens of live scalars)
@@ -308,13 +331,9 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     const int xq_tile = (xq % XT_DATAX) / XT_BDIM;
     const bool pre_lane = xq > 8 && xq < w - 8 && xq_tile != 1;
     const bool pre_lane0 = pre_lane && xq_tile == 0; // rows with y mod 32 = 30: see alias_prefilter_kernel
-    int yo_next = y0; // image row of the next completed output row
     if (lane < S) lq_n[lane] = 0;
 
     // ---- source fetch of one row into registers ----
-    // mode 0: lane j < 22 holds staged floats 4j..4j+3
-    // mode 1: lane j holds staged float j (.x) and, j < 24, staged float 64+j (.y)
-    // mode 2: lane j < 44 holds staged floats 2j (.x) and 2j+1 (.z)
     // The loads are unconditional (clamped addresses) and pixels outside the
     // image are zeroed with bit masks, not selects: a select on the loaded
     // value lets the compiler sink the load under the condition and wait for
@@ -363,17 +382,13 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     }
 
     Row g[FZ_PF];
-#pragma unroll
-    for (int q = 0; q < FZ_PF; ++q) g[q] = fetch();
-    stage(0, g[0]);
-    g[0] = fetch();
 
-    // One chunk of 20 input rows.  GUARD = false is the steady state: straight
-    // line, every row completes one output row.  GUARD = true also serves the
-    // first chunk of a strip (rows 0..17 complete no output) and the last one
-    // (which may run past the strip's last input row) with run-time tests.
-    auto chunk = [&](auto guard_c, const int rb) __attribute__((always_inline)) {
-        constexpr bool GUARD = decltype(guard_c)::value;
+    // lanes the detector pre-filter may queue, as wave masks
+    const unsigned long long pre_mask = __ballot(pre_lane), pre_mask0 = __ballot(pre_lane0);
+
+    // One chunk of 20 input rows, straight line.  Input row r of the strip
+    // completes output row y0 + r - 18.
+    auto chunk = [&](const int rb) __attribute__((always_inline)) {
         static_for<COL_RING>([&](auto rr_c) __attribute__((always_inline)) {
             constexpr int rr = decltype(rr_c)::value;
             const int r = rb + rr;
@@ -382,67 +397,75 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
             // row r+1 goes to the other LDS slot; its register is refilled with row r+1+FZ_PF
             stage((rr + 1) & 1, g[(rr + 1) % FZ_PF]);
             g[(rr + 1) % FZ_PF] = fetch();
-            if (!GUARD || r < nin) {
-                float win[TAPS];
+            float win[TAPS + 1]; // the 20th value only completes the last register pair
 #pragma unroll
-                for (int k = 0; k < 10; ++k) win[k] = lds[rr & 1][lane + 3 + k];
-                float2v vp[NPAIR];
-                float vs = 0.f;
+            for (int k = 0; k < 10; ++k) win[k] = lds[rr & 1][lane + 3 + k];
+            float2v vp[NPAIR];
+            float vs = 0.f;
 #pragma unroll
-                for (int j = 0; j < NPAIR; ++j) vp[j] = float2v{0.f, 0.f};
+            for (int j = 0; j < NPAIR; ++j) vp[j] = float2v{0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < TAPS; ++k) {
-                    if (k == 10) {
-                        __builtin_amdgcn_sched_barrier(0);
+            for (int k = 0; k < TAPS; ++k) {
+                if (k == 10) {
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int q = 10; q < TAPS; ++q) win[q] = lds[rr & 1][lane + 3 + q];
-                    }
-                    const float2v wk = float2v{win[k], win[k]};
-#pragma unroll
-                    for (int j = 0; j < NPAIR; ++j) vp[j] = pk_fma(tap2(taps, j, k), wk, vp[j]);
-                    if (ODD) vs = __builtin_fmaf(tap1(taps, NP - 1, k), win[k], vs);
+                    for (int q = 10; q < TAPS + 1; ++q) win[q] = lds[rr & 1][lane + 3 + q];
+                    // a packed operand names a register pair: without a defined partner the
+                    // last window value may share its pair with a load still in flight, and
+                    // the use would wait for all of memory
+                    asm volatile("" ::"v"(win[TAPS]));
                 }
+                const float2v wk = float2v{win[k], win[k]};
 #pragma unroll
-                for (int k = 0; k < TAPS; ++k) {
-                    const int slot = (rr - k + COL_RING) % COL_RING;
+                for (int j = 0; j < NPAIR; ++j) vp[j] = pk_fma(tap2(taps, j, k), wk, vp[j]);
+                if (ODD) vs = __builtin_fmaf(tap1(taps, NP - 1, k), win[k], vs);
+            }
 #pragma unroll
-                    for (int j = 0; j < NPAIR; ++j)
-                        accp[j][slot] = pk_fma(tap2(taps, j, k), vp[j], k == 0 ? float2v{0.f, 0.f} : accp[j][slot]);
-                    if (ODD) accs[slot] = __builtin_fmaf(tap1(taps, NP - 1, k), vs, k == 0 ? 0.f : accs[slot]);
-                }
-                if (!GUARD || r >= 2 * RADIUS) { // output row y0 + r - 18 is complete
-                    const int e = (rr - 2 * RADIUS + COL_RING) % COL_RING;
-                    float b[NP];
+            for (int k = 0; k < TAPS; ++k) {
+                const int slot = (rr - k + COL_RING) % COL_RING;
 #pragma unroll
-                    for (int j = 0; j < NPAIR; ++j) {
-                        b[2 * j] = accp[j][e].x;
-                        b[2 * j + 1] = accp[j][e].y;
-                    }
-                    if (ODD) b[NP - 1] = accs[e];
+                for (int j = 0; j < NPAIR; ++j)
+                    accp[j][slot] = pk_fma(tap2(taps, j, k), vp[j], k == 0 ? float2v{0.f, 0.f} : accp[j][slot]);
+                if (ODD) accs[slot] = __builtin_fmaf(tap1(taps, NP - 1, k), vs, k == 0 ? 0.f : accs[slot]);
+            }
+            // output row y0 + r - 18 is complete if it belongs to this strip
+            const bool valid = r >= 2 * RADIUS && r < nin; // wave-uniform
+            const int vo = out_lane | (valid ? 0 : (int)FZ_DROP);
+            constexpr int e = (rr - 2 * RADIUS + COL_RING) % COL_RING;
+            float b[NP];
 #pragma unroll
-                    for (int i = 1; i <= S; ++i)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b[i]), bl_rs, out_lane,
-                                                              (int)(out_row + (i - 1) * plane_b), 0);
+            for (int j = 0; j < NPAIR; ++j) {
+                b[2 * j] = accp[j][e].x;
+                b[2 * j + 1] = accp[j][e].y;
+            }
+            if (ODD) b[NP - 1] = accs[e];
 #pragma unroll
-                    for (int i = 0; i < NP - 1; ++i)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b[i] - b[i + 1]), dg_rs, out_lane,
-                                                              (int)(out_row + i * plane_b), 0);
-                    out_row += (unsigned)p * 4u;
-                    // detector pre-filter: queue the pixels that pass the contrast test
-                    // (rare).  Pixels whose centre cell the reference reads through an
-                    // aliased shared-memory cell (y mod 32 = 31, and the right tile at
-                    // y mod 32 = 30) are left to alias_prefilter_kernel.  No global memory
-                    // is touched here, so the counted waits of the row loop stay exact.
-                    const int yo = yo_next++;
-                    if (pre && yo > 8 && yo < h - 8 && (yo & 31) < 31) { // wave-uniform
-                        const bool lane_pre = (yo & 31) == 30 ? pre_lane0 : pre_lane;
+            for (int i = 1; i <= S; ++i)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b[i]), bl_rs, vo,
+                                                      (int)(out_row + (i - 1) * plane_b), 0);
 #pragma unroll
-                        for (int i = 0; i < S; ++i) {
-                            if (lane_pre && fabsf(b[i + 1] - b[i + 2]) > contrast) {
-                                const unsigned slot = atomicAdd(&lq_n[i], 1u);
-                                if (slot < PQ_CAP) lq[i][slot] = (unsigned)xq | ((unsigned)yo << 16);
-                            }
-                        }
+            for (int i = 0; i < NP - 1; ++i)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b[i] - b[i + 1]), dg_rs, vo,
+                                                      (int)(out_row + i * plane_b), 0);
+            out_row += valid ? (unsigned)p * 4u : 0u;
+            // detector pre-filter: queue the pixels that pass the contrast test
+            // (rare).  Pixels whose centre cell the reference reads through an
+            // aliased shared-memory cell (y mod 32 = 31, and the right tile at
+            // y mod 32 = 30) are left to alias_prefilter_kernel.  No global memory
+            // is touched here, so the counted waits of the row loop stay exact.
+            const int yo = y0 + r - 2 * RADIUS;
+            if (pre && valid && yo > 8 && yo < h - 8 && (yo & 31) < 31) { // wave-uniform
+                const unsigned long long lanes = (yo & 31) == 30 ? pre_mask0 : pre_mask;
+#pragma unroll
+                for (int i = 0; i < S; ++i) {
+                    const unsigned long long hits = __ballot(fabsf(b[i + 1] - b[i + 2]) > contrast) & lanes;
+                    if (hits) {
+                        unsigned base = 0;
+                        if (lane == 0) base = atomicAdd(&lq_n[i], (unsigned)__popcll(hits));
+                        base = __shfl(base, 0);
+                        const unsigned slot = base + __popcll(hits & ((1ull << lane) - 1ull));
+                        if (((hits >> lane) & 1ull) && slot < PQ_CAP)
+                            lq[i][slot] = (unsigned)xq | ((unsigned)yo << 16);
                     }
                 }
             }
@@ -476,13 +499,16 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
         for (int i = 0; i < S; ++i) fill = max(fill, lq_n[i]);
         if (__builtin_amdgcn_readfirstlane(fill) > PQ_CAP / 2) flush();
     };
-    chunk(std::true_type{}, 0);
-    int rb = COL_RING;
-    for (; rb + COL_RING <= nin; rb += COL_RING) {
-        chunk(std::false_type{}, rb);
-        flush_if_filling();
-    }
-    if (rb < nin) chunk(std::true_type{}, rb);
+    // prologue: the first FZ_PF rows
+#pragma unroll
+    for (int q = 0; q < FZ_PF; ++q) g[q] = fetch();
+    stage(0, g[0]);
+    g[0] = fetch();
+    // The first chunk stands outside the loop: the loop is then entered in the
+    // counter state its own back edge produces, and the waits inside it are
+    // exact on every trip.
+    chunk(0);
+    for (int rb = COL_RING; rb < nin; rb += COL_RING) chunk(rb);
     if (pre) flush();
 }
 
@@ -1392,7 +1418,7 @@ int hl_pyramid(const float *src, int src_w, int src_h, int src_pitch, long src_s
     if (subsample ? (w != (src_w + 1) / 2 || h != (src_h + 1) / 2) : (w != src_w || h != src_h))
         return -1006;
     // 32-bit byte offsets inside one image's source, blur and DoG planes
-    if ((long)p * h * (n_scales + 2) * 4 > 0xffffffffL || (long)src_pitch * src_h * 4 > 0xffffffffL)
+    if ((long)p * h * (n_scales + 2) * 4 >= (long)FZ_DROP || (long)src_pitch * src_h * 4 > 0xffffffffL)
         return -1007;
     if (queue && (!qcount || qcap < 1 || w > 65535 || h > 65535)) return -1008;
     // strip height 20*m - 18: every strip recomputes an 18-row apron, so strips are as

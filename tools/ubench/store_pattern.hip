@@ -5,7 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
-template <int NPL, bool READ>
+template <int NPL, bool READ, int NT>
 __global__ __launch_bounds__(64) void strips(float *out, const float *in, int p, int h, int rows, long img_stride)
 {
     const int lane = threadIdx.x;
@@ -17,9 +17,12 @@ __global__ __launch_bounds__(64) void strips(float *out, const float *in, int p,
     const long plane = (long)p * h;
     float v = (float)lane;
     for (int y = y0; y < y1; ++y) {
-        if (READ) v += s[(long)y * p + x];
+        if (READ) v += (NT & 2) ? __builtin_nontemporal_load(&s[(long)y * p + x]) : s[(long)y * p + x];
 #pragma unroll
-        for (int i = 0; i < NPL; ++i) o[i * plane + (long)y * p + x] = v + i;
+        for (int i = 0; i < NPL; ++i) {
+            if (NT & 1) __builtin_nontemporal_store(v + i, &o[i * plane + (long)y * p + x]);
+            else o[i * plane + (long)y * p + x] = v + i;
+        }
     }
 }
 
@@ -42,21 +45,31 @@ int main()
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const double bytes = (double)img_stride * nimg * 4;
-    for (int rows : {102, 182}) {
-        for (int rd = 0; rd < 2; ++rd) {
+    for (int rows : {182}) {
+        for (int rd = 0; rd < 8; ++rd) {
             dim3 grid(w / 64, (h + rows - 1) / rows, nimg);
             float best = 1e9;
             for (int it = 0; it < 4; ++it) {
                 hipEventRecord(e0, 0);
-                if (rd) hipLaunchKernelGGL((strips<NPL, true>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride);
-                else hipLaunchKernelGGL((strips<NPL, false>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride);
+                switch (rd) {
+                case 0: hipLaunchKernelGGL((strips<NPL, false, 0>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride); break;
+                case 1: hipLaunchKernelGGL((strips<NPL, true, 0>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride); break;
+                case 2: hipLaunchKernelGGL((strips<NPL, false, 1>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride); break;
+                case 3: hipLaunchKernelGGL((strips<NPL, true, 1>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride); break;
+                case 4: hipLaunchKernelGGL((strips<NPL, true, 2>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride); break;
+                case 5: hipLaunchKernelGGL((strips<NPL, true, 3>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride); break;
+                case 6: hipLaunchKernelGGL((strips<5, true, 0>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride); break;
+                case 7: hipLaunchKernelGGL((strips<4, true, 0>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride); break;
+                }
                 hipEventRecord(e1, 0);
                 hipEventSynchronize(e1);
                 float ms;
                 hipEventElapsedTime(&ms, e0, e1);
                 if (it && ms < best) best = ms;
             }
-            printf("strip stores rows=%d read=%d: %.3f ms  write %.2f TB/s\n", rows, rd, best, bytes / best / 1e9);
+            static const char *nm[] = {"6pl store", "6pl store+load", "6pl nt-store", "6pl nt-store+load", "6pl store+nt-load", "6pl nt-store+nt-load", "5pl store+load", "4pl store+load"};
+            const double by = bytes * (rd == 6 ? 5.0 / 6 : rd == 7 ? 4.0 / 6 : 1.0);
+            printf("%-22s rows=%d: %.3f ms  write %.2f TB/s\n", nm[rd], rows, best, by / best / 1e9);
         }
     }
     {
