@@ -39,16 +39,17 @@ def octave_pixels(w, h, n_oct):
 def algorithmic_bytes(s):
     """Bytes per pixel per octave, float32 planes.
 
-    `pyramid`: what the fused row+column kernel has to move: read the octave
-    base, write S blur planes, S+2 DoG planes and a quarter plane (next base).
+    `pyramid`: what the fused row+column kernel has to move: read the octave's
+    source once, write the S+3 blur planes (DoG values are formed by their
+    readers; the next octave reads blur plane S in place).
     `two_pass`: the same work as two kernels with the S+3 row-blurred planes
-    written to and re-read from HBM (the accounting of a separable two-pass
-    design), kept for comparison.
-    `detect`: the S+2 DoG planes are the detector's input."""
+    written to and re-read from HBM and DoG planes stored (the accounting of a
+    separable two-pass design), kept for comparison.
+    `detect`: the dense detector reads the S+3 blur planes."""
     return {
-        "pyramid": (1 + s + (s + 2) + 0.25) * 4.0,
+        "pyramid": (1 + (s + 3)) * 4.0,
         "two_pass": (1 + (s + 3)) * 4.0 + ((s + 3) + s + (s + 2) + 0.25) * 4.0,
-        "detect": (s + 2) * 4.0,
+        "detect": (s + 3) * 4.0,
     }
 
 
@@ -197,8 +198,8 @@ def main():
         }
         if dom == "pyramid":
             out["roofline"]["two_pass_equivalent_GBps"] = achieved / 1e9 * ab["two_pass"] / ab["pyramid"]
-            out["roofline"]["note"] = ("the fused kernel is FP32 vector-issue bound (190 FMA/px); the HBM "
-                                       "fraction is quoted on its own 29 B/px, a two-pass design moves 69 B/px")
+            out["roofline"]["note"] = ("fused row+column pass: 24 B/px moved (a two-pass design with stored DoG "
+                                       "planes moves 69 B/px) beside 190 FP32 FMA/px")
         out["kernels_ms_per_image"] = {k: v["ms_total"] / (args.batch * args.steps) for k, v in kern.items()}
         # HBM-side bytes per launch of the dominant kernel from rocprofv3 counters (separate
         # FETCH_SIZE / WRITE_SIZE passes over this same command, tools/prof_pmc.sh), if committed

@@ -28,8 +28,7 @@ typedef struct {
 typedef struct {
     int w, h, p;        /* internal pitch p */
     int qcap;           /* capacity of each scale's contrast-candidate queue */
-    long blur_off;      /* S kept blur planes (plane index 1..S) */
-    long dog_off;       /* S+2 DoG planes */
+    long blur_off;      /* the S+3 blur planes, plane 0 first */
     long queue_off;     /* first of the octave's S queues, in words, inside an image's queue block */
 } hl_octave;
 
@@ -93,8 +92,8 @@ int hl_col_blur_dog(const float *tmp, long tmp_stride, float *blur, long blur_st
                     int all_planes, float *dog, long dog_stride, float *next_base,
                     long next_stride, int next_p, int w, int p, int h, int n_scales, int nimg,
                     const hl_taps *taps, void *stream);
-/* fused row pass + column pass: source -> blur planes 1..S and S+2 DoG planes,
- * no intermediate in HBM.  subsample != 0: the source is the previous octave's
+/* fused row pass + column pass: source -> the S+3 blur planes, no intermediate
+ * in HBM (DoG plane i is blur plane i minus blur plane i+1, formed by its readers).  subsample != 0: the source is the previous octave's
  * blur plane S (src_w x src_h) and is read at its even rows and columns, so
  * w = ceil(src_w/2), h = ceil(src_h/2).  p must be a multiple of 64: columns
  * [w, p) of the destination planes are written with don't-care values.
@@ -103,7 +102,7 @@ int hl_col_blur_dog(const float *tmp, long tmp_stride, float *blur, long blur_st
  * queue[i*qcap + k], count in qcount[group0 + i]; a count above qcap means the
  * queue is incomplete and the dense detector must redo that scale. */
 int hl_pyramid(const float *src, int src_w, int src_h, int src_pitch, long src_stride, int subsample,
-               float *blur, long blur_stride, float *dog, long dog_stride, int w, int p, int h,
+               float *blur, long blur_stride, int w, int p, int h,
                int n_scales, int nimg, const hl_taps *taps, float contrast, unsigned *queue,
                long queue_stride, unsigned *qcount, long qcount_stride, int qcap, int group0,
                void *stream);

@@ -32,7 +32,7 @@ typedef struct {
     float *arena;
     long arena_stride; /* floats per image */
     int ow[SIFT_MAX_OCTAVES], oh[SIFT_MAX_OCTAVES], op[SIFT_MAX_OCTAVES];
-    long blur_off[SIFT_MAX_OCTAVES], dog_off[SIFT_MAX_OCTAVES];
+    long blur_off[SIFT_MAX_OCTAVES];
     long queue_off[SIFT_MAX_OCTAVES]; /* words, inside one image's queue block */
     int qcap[SIFT_MAX_OCTAVES];
     long queue_stride;                /* words per image */
@@ -256,11 +256,11 @@ static int ensure_slot_counter(int dev)
     return 0;
 }
 
-/* Plans (or re-plans) the per-image arena: per octave the S+2 DoG planes and the
- * S kept blur planes (1..S: the Hessian, the gradients and the next octave read
- * nothing else).  Every octave has its own DoG planes so that all pyramid
- * passes can be queued back to back and detection can run once, over all
- * octaves, afterwards. */
+/* Plans (or re-plans) the per-image arena: per octave the S+3 blur planes.  A DoG
+ * value is formed where it is read (one subtraction of two neighbouring planes,
+ * cudaSiftH.cu:190), so DoG planes are never stored.  Every octave has its own
+ * planes so that all pyramid passes can be queued back to back and detection
+ * can run once, over all octaves, afterwards. */
 static int ensure_arena(slot_ctx *c, int w, int h, int oct0, int nimg)
 {
     const int S = g_params.n_scales, O = g_params.n_octaves, cap = g_params.max_points;
@@ -280,10 +280,8 @@ static int ensure_arena(slot_ctx *c, int w, int h, int oct0, int nimg)
         c->ow[oi] = ww;
         c->oh[oi] = hh;
         c->op[oi] = (o == oct0) ? ialignup(ww, 64) : ialignup(ww, 128); /* cudaSiftH.cu:46 */
-        c->dog_off[oi] = off;
-        off += lalign((long)c->op[oi] * hh * (S + 2), 64);
         c->blur_off[oi] = off;
-        off += lalign((long)c->op[oi] * hh * S, 64);
+        off += lalign((long)c->op[oi] * hh * (S + 3), 64);
         c->qcap[oi] = qc;
         c->queue_off[oi] = qoff;
         qoff += (long)S * qc;
@@ -350,19 +348,18 @@ static int enqueue_extract(slot_ctx *c, SiftPoint *pts, unsigned char *meta, con
         da.oct[oi].p = pp;
         da.oct[oi].qcap = c->qcap[oi];
         da.oct[oi].blur_off = c->blur_off[oi];
-        da.oct[oi].dog_off = c->dog_off[oi];
         da.oct[oi].queue_off = c->queue_off[oi];
         da.band0[oi + 1] = da.band0[oi] + idivup(hh, 32);
         da.dense0[oi + 1] = da.dense0[oi] + idivup(ww, 256) * idivup(hh, 32);
         if (o == oct0)
             r = hl_pyramid(imgs, ww, hh, pitch, img_stride, 0, A + c->blur_off[oi], AS,
-                           A + c->dog_off[oi], AS, ww, pp, hh, S, nimg, &g_taps, da.contrast,
+                           ww, pp, hh, S, nimg, &g_taps, da.contrast,
                            prefilter ? c->queue + c->queue_off[oi] : NULL, c->queue_stride, queued,
                            COUNT_WORDS, c->qcap[oi], oi * S, stream);
         else /* cudaSiftH.cu:50-52: the next octave is the even pixels of blur plane S */
-            r = hl_pyramid(A + c->blur_off[oi - 1] + (long)(S - 1) * c->op[oi - 1] * c->oh[oi - 1],
+            r = hl_pyramid(A + c->blur_off[oi - 1] + (long)S * c->op[oi - 1] * c->oh[oi - 1],
                            c->ow[oi - 1], c->oh[oi - 1], c->op[oi - 1], AS, 1, A + c->blur_off[oi],
-                           AS, A + c->dog_off[oi], AS, ww, pp, hh, S, nimg, &g_taps, da.contrast,
+                           AS, ww, pp, hh, S, nimg, &g_taps, da.contrast,
                            prefilter ? c->queue + c->queue_off[oi] : NULL, c->queue_stride, queued,
                            COUNT_WORDS, c->qcap[oi], oi * S, stream);
         if (r) return fail_hl(r, "pyramid pass");

@@ -274,8 +274,7 @@ constexpr int XT_PLANE_OFF = 3168;
 template <int S, int SRC_MODE>
 __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     const float *__restrict__ src, int src_w, int src_h, int src_pitch, long src_stride,
-    float *__restrict__ blur, long blur_stride, float *__restrict__ dog, long dog_stride, int w,
-    int p, int h, int rows, hl_taps taps, float contrast, unsigned *__restrict__ queue,
+    float *__restrict__ blur, long blur_stride, int w, int p, int h, int rows, hl_taps taps, float contrast, unsigned *__restrict__ queue,
     long queue_stride, unsigned *__restrict__ qcount, long qcount_stride, int qcap, int group0)
 {
     constexpr int NP = S + 3;
@@ -314,9 +313,7 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(src), 0, (int)(unsigned)min((long)src_pitch * src_h * 4, 0xffffffffL), 0x00020000);
     const __amdgpu_buffer_rsrc_t bl_rs = __builtin_amdgcn_make_buffer_rsrc(
-        blur + z * blur_stride, 0, (int)(unsigned)min(plane * S * 4, (long)FZ_DROP), 0x00020000);
-    const __amdgpu_buffer_rsrc_t dg_rs = __builtin_amdgcn_make_buffer_rsrc(
-        dog + z * dog_stride, 0, (int)(unsigned)min(plane * (S + 2) * 4, (long)FZ_DROP), 0x00020000);
+        blur + z * blur_stride, 0, (int)(unsigned)min(plane * NP * 4, (long)FZ_DROP), 0x00020000);
     // destination of the next completed output row; advanced row by row (a
     // loop-carried pointer: offsets formed from the unrolled row index would be
     // hoisted out of the loop as dozens of live scalars)
@@ -440,12 +437,8 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
             }
             if (ODD) b[NP - 1] = accs[e];
 #pragma unroll
-            for (int i = 1; i <= S; ++i)
+            for (int i = 0; i < NP; ++i)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b[i]), bl_rs, vo,
-                                                      (int)(out_row + (i - 1) * plane_b), 0);
-#pragma unroll
-            for (int i = 0; i < NP - 1; ++i)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b[i] - b[i + 1]), dg_rs, vo,
                                                       (int)(out_row + i * plane_b), 0);
             out_row += valid ? (unsigned)p * 4u : 0u;
             // detector pre-filter: queue the pixels that pass the contrast test
@@ -458,7 +451,7 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
                 const unsigned long long lanes = (yo & 31) == 30 ? pre_mask0 : pre_mask;
 #pragma unroll
                 for (int i = 0; i < S; ++i) {
-                    const unsigned long long hits = __ballot(fabsf(b[i + 1] - b[i + 2]) > contrast) & lanes;
+                    const unsigned long long hits = __ballot(fabsf(__fsub_rn(b[i + 1], b[i + 2])) > contrast) & lanes;
                     if (hits) {
                         unsigned base = 0;
                         if (lane == 0) base = atomicAdd(&lq_n[i], (unsigned)__popcll(hits));
@@ -529,7 +522,7 @@ __device__ __forceinline__ float zpad(const float *pl, int w, int p, int h, int 
 // value found at (sx,sy) of tile s by a thread of block (bx,by): the head of
 // tile s+1 has overwritten the tail of tile s (cudaSiftD.cu:239-261).
 // Branch-free, so independent reads issue back to back.
-__device__ __forceinline__ float tile_read(const float *d3, long plane, int w, int p, int h, int bx,
+__device__ __forceinline__ float tile_read(const float *b3, long plane, int w, int p, int h, int bx,
                                            int by, int s, int sx, int sy)
 {
     const int lin = sx + XT_SDIMX * sy;
@@ -542,57 +535,97 @@ __device__ __forceinline__ float tile_read(const float *d3, long plane, int w, i
     sy = moved ? sy2 : sy;
     const int x = XT_DATAX * bx - 1 + sx, y = XT_BDIM * by - 1 + sy;
     const bool in = x >= 0 && x < w && y >= 0 && y < h;
-    const float v = d3[s * plane + (in ? x + (long)p * y : 0)];
+    const float *c = b3 + s * plane + (in ? x + (long)p * y : 0);
+    const float v = __fsub_rn(c[0], c[plane]); // DoG plane s (cudaSiftH.cu:190)
     return in ? v : 0.f;
 }
 
-__device__ __forceinline__ float center_value(const float *d3, long plane, int w, int p, int h, int x, int y)
+__device__ __forceinline__ float center_value(const float *b3, long plane, int w, int p, int h, int x, int y)
 {
-    return tile_read(d3, plane, w, p, h, x / XT_DATAX, y >> 5, 1, 1 + x % XT_DATAX, 1 + (y & 31));
+    return tile_read(b3, plane, w, p, h, x / XT_DATAX, y >> 5, 1, 1 + x % XT_DATAX, 1 + (y & 31));
 }
 
-// 27-cell rank of cudaSiftD.cu:271-284: sum of +1 where centre >= cell, else -1
-__device__ int pixel_rank(const float *d3, long plane, int w, int p, int h, int x, int y)
+struct __attribute__((packed, aligned(4))) float3u {
+    float a, b, c;
+};
+
+// 27-cell rank of cudaSiftD.cu:271-284: sum of +1 where centre >= cell, else -1.
+// rank_plain: no aliased cell in reach and no image border, i.e. the plain
+// neighbourhood in three DoG planes, from four blur planes.  Twelve 12-byte
+// loads (three neighbours of one row of one plane each) instead of 36 single ones.
+__device__ __forceinline__ bool rank_is_plain(int w, int h, int x, int y)
 {
+    return (y & 31) < 29 && x > 0 && x < w - 1 && y > 0 && y < h - 1;
+}
+
+__device__ __forceinline__ int rank_plain(const float *__restrict__ b3, long plane, int p, int x, int y)
+{
+    const float *c = b3 + x + (long)p * y;
+    float v[4][3][3];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int m = -1; m < 2; ++m) {
+            const float3u t = *reinterpret_cast<const float3u *>(c + s * plane + m * p - 1);
+            v[s][m + 1][0] = t.a, v[s][m + 1][1] = t.b, v[s][m + 1][2] = t.c;
+        }
+    const float pv = __fsub_rn(v[1][1][1], v[2][1][1]);
     int r = 0;
-    if ((y & 31) < 29 && x > 0 && x < w - 1 && y > 0 && y < h - 1) {
-        // no aliased cell in reach and no image border: the plain neighbourhood
-        const float *c = d3 + x + (long)p * y;
-        const float pv = c[plane];
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
+    for (int s = 0; s < 3; ++s)
 #pragma unroll
-            for (int m = -1; m < 2; ++m)
+        for (int m = 0; m < 3; ++m)
 #pragma unroll
-                for (int l = -1; l < 2; ++l) r += (pv >= c[s * plane + m * p + l]) ? 1 : -1;
-        return r;
-    }
+            for (int l = 0; l < 3; ++l) r += (pv >= __fsub_rn(v[s][m][l], v[s + 1][m][l])) ? 1 : -1;
+    return r;
+}
+
+// the same through the reference's tile addressing, aliased cells and zero padding included
+__device__ __forceinline__ int rank_tiled(const float *__restrict__ b3, long plane, int w, int p, int h, int x, int y)
+{
     const int bx = x / XT_DATAX, by = y >> 5;
     const int sx = 1 + x % XT_DATAX, sy = 1 + (y & 31);
-    const float pv = tile_read(d3, plane, w, p, h, bx, by, 1, sx, sy);
+    const float pv = tile_read(b3, plane, w, p, h, bx, by, 1, sx, sy);
+    int r = 0;
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
         for (int m = -1; m < 2; ++m)
 #pragma unroll
             for (int l = -1; l < 2; ++l)
-                r += (pv >= tile_read(d3, plane, w, p, h, bx, by, s, sx + l, sy + m)) ? 1 : -1;
+                r += (pv >= tile_read(b3, plane, w, p, h, bx, by, s, sx + l, sy + m)) ? 1 : -1;
     return r;
+}
+
+// in the right tile of a 96-wide block the rank is carried over from the two
+// tiles to the left: ranks at x, x-32 and x-64 are added
+__device__ __forceinline__ int rank_count(int x) { return (x % XT_DATAX) >= 2 * XT_BDIM ? 3 : 1; }
+
+// true if every rank of the candidate can be taken on the plain neighbourhood
+__device__ __forceinline__ bool candidate_is_plain(int w, int h, int x, int y)
+{
+    return rank_is_plain(w, h, x, y) && (rank_count(x) == 1 || x - 64 > 0);
 }
 
 // Full acceptance test of one contrast candidate (cudaSiftD.cu:271-293 after the
 // contrast clause): rank 9 with the carry of the reference's tile loop, then
 // the edge test on a Hessian of blur plane i+1 (hessianKernel, cudaSiftD.cu:405-419).
-__device__ bool accept_candidate(const float *d3, const float *blur_i, long plane, int w, int p,
-                                 int h, float edge_limit, int x, int y)
+// PLAIN: the caller has checked candidate_is_plain.
+template <bool PLAIN>
+__device__ __forceinline__ bool accept_candidate(const float *__restrict__ b3, long plane, int w, int p,
+                                                 int h, float edge_limit, int x, int y)
 {
-    int r = pixel_rank(d3, plane, w, p, h, x, y);
-    if ((x % XT_DATAX) >= 2 * XT_BDIM) { // the rank is carried over from the two tiles to the left
-        r += pixel_rank(d3, plane, w, p, h, x - 64, y);
-        r += pixel_rank(d3, plane, w, p, h, x - 32, y);
+    const int n_ranks = rank_count(x);
+    int r = 0;
+    for (int t = 0; t < n_ranks; ++t) {
+        const int xt = x - 32 * t;
+        if (PLAIN)
+            r += rank_plain(b3, plane, p, xt, y);
+        else
+            r += rank_is_plain(w, h, xt, y) ? rank_plain(b3, plane, p, xt, y) : rank_tiled(b3, plane, w, p, h, xt, y);
     }
     if (r != 9) return false;
-    const float *b = blur_i + x + (long)p * y;
+    const float *b = b3 + plane + x + (long)p * y; // blur plane i+1
     const float c = b[0];
     float Dxx = -2.f * c;
     Dxx += b[-1];
@@ -664,22 +697,24 @@ __global__ __launch_bounds__(256) void alias_prefilter_kernel(const float *__res
     const int yC = (unit - a.band0[oi]) * 32, yA = yC - 1; // row 0 is a source row too (targets at y = 31)
     const int z = blockIdx.z;
     const long plane = (long)p * h;
-    const float *dog = arena + z * arena_stride + oc.dog_off;
+    const float *blur = arena + z * arena_stride + oc.blur_off;
     queue += z * queue_stride + oc.queue_off;
     qcount += z * qcount_stride + oi * S;
     const bool in_x = xs4 < w;
 
 #pragma unroll
     for (int i = 0; i < S; ++i) {
-        const float *src = dog + (i + 2) * plane;
+        const float *src = blur + (i + 2) * plane; // DoG plane i+2 = blur plane i+2 - blur plane i+3
         float va[4] = {0.f, 0.f, 0.f, 0.f}, vc[4] = {0.f, 0.f, 0.f, 0.f};
         if (in_x && yA >= 0) {
             const float4 t = *reinterpret_cast<const float4 *>(src + xs4 + (long)p * yA);
-            va[0] = t.x, va[1] = t.y, va[2] = t.z, va[3] = t.w;
+            const float4 u = *reinterpret_cast<const float4 *>(src + plane + xs4 + (long)p * yA);
+            va[0] = __fsub_rn(t.x, u.x), va[1] = __fsub_rn(t.y, u.y), va[2] = __fsub_rn(t.z, u.z), va[3] = __fsub_rn(t.w, u.w);
         }
         if (in_x && yC < h) {
             const float4 t = *reinterpret_cast<const float4 *>(src + xs4 + (long)p * yC);
-            vc[0] = t.x, vc[1] = t.y, vc[2] = t.z, vc[3] = t.w;
+            const float4 u = *reinterpret_cast<const float4 *>(src + plane + xs4 + (long)p * yC);
+            vc[0] = __fsub_rn(t.x, u.x), vc[1] = __fsub_rn(t.y, u.y), vc[2] = __fsub_rn(t.z, u.z), vc[3] = __fsub_rn(t.w, u.w);
         }
         // up to three targets per source pixel: (a) and (b) from row yA, (c) from row yC
 #pragma unroll
@@ -718,23 +753,59 @@ __global__ __launch_bounds__(256) void verify_kernel(const float *__restrict__ a
     const unsigned n = qcount[z * qcount_stride + g];
     if (n == 0 || n > (unsigned)oc.qcap) return; // overflow: the dense kernel takes this group
     const long plane = (long)oc.p * oc.h;
-    const float *d3 = arena + z * arena_stride + oc.dog_off + i * plane;
-    const float *bi = arena + z * arena_stride + oc.blur_off + i * plane;
+    const float *b3 = arena + z * arena_stride + oc.blur_off + i * plane; // blur planes i..i+3
     queue += z * queue_stride + oc.queue_off + (long)i * oc.qcap;
     cand += z * cand_stride + (long)g * a.cap;
     counts += z * counts_stride + g;
+    // Candidates that need the tile addressing (a tenth of them, spread over
+    // every wave) are set aside in LDS and handled in full batches, so that the
+    // long path runs once per 256 of them instead of once per wave.
+    __shared__ unsigned slow_xy[512];
+    __shared__ unsigned slow_n;
+    if (threadIdx.x == 0) slow_n = 0;
+    __syncthreads();
+    auto run_slow = [&](unsigned first, unsigned count) __attribute__((always_inline)) { // block-uniform arguments
+        bool hit = false;
+        unsigned xy = 0;
+        if (threadIdx.x < count) {
+            xy = slow_xy[first + threadIdx.x];
+            hit = accept_candidate<false>(b3, plane, oc.w, oc.p, oc.h, a.edge_limit, (int)(xy & 0xffffu),
+                                          (int)(xy >> 16));
+        }
+        append_hits(hit, xy, lane, counts, cand, a.cap);
+    };
     const unsigned step = gridDim.x * 256;
     for (unsigned e0 = blockIdx.x * 256; e0 < n; e0 += step) { // block-uniform trip count
         const unsigned e = e0 + threadIdx.x;
-        bool hit = false;
+        bool hit = false, slow = false;
         unsigned xy = 0;
         if (e < n) {
             xy = queue[e];
-            hit = accept_candidate(d3, bi, plane, oc.w, oc.p, oc.h, a.edge_limit, (int)(xy & 0xffffu),
-                                   (int)(xy >> 16));
+            const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+            if (candidate_is_plain(oc.w, oc.h, x, y))
+                hit = accept_candidate<true>(b3, plane, oc.w, oc.p, oc.h, a.edge_limit, x, y);
+            else
+                slow = true;
         }
         append_hits(hit, xy, lane, counts, cand, a.cap);
+        const unsigned long long sm = __ballot(slow);
+        if (sm) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&slow_n, (unsigned)__popcll(sm));
+            base = __shfl(base, 0);
+            if (slow) slow_xy[base + __popcll(sm & ((1ull << lane) - 1ull))] = xy;
+        }
+        __syncthreads();
+        const unsigned pending = slow_n; // at most 255 kept + 256 new
+        if (pending >= 256) {
+            run_slow(pending - 256, 256);
+            __syncthreads();
+            if (threadIdx.x == 0) slow_n = pending - 256;
+            __syncthreads();
+        }
     }
+    const unsigned pending = slow_n;
+    if (pending) run_slow(0, pending);
 }
 
 // Dense detector.  One wave per 256-pixel wide, 8-row tall block of pixels,
@@ -774,7 +845,6 @@ __global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ a
         const int x4 = (u % xblocks) * 256 + 4 * lane;
         const int y0 = ((u / xblocks) * 4 + wv) * DET_ROWS;
         const long plane = (long)p * h;
-        const float *dog = arena + z * arena_stride + oc.dog_off;
         const float *blur = arena + z * arena_stride + oc.blur_off;
         // 96 and 32 are multiples of 4, so the four pixels of a lane share a tile;
         // a pixel in the middle tile can never reach rank 9
@@ -785,7 +855,7 @@ __global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ a
         for (int i = 0; i < S; ++i) {
             const int g = oi * S + i;
             if (gate && gate[g] <= (unsigned)oc.qcap) continue; // block-uniform
-            const float *d3 = dog + i * plane;
+            const float *b3 = blur + i * plane; // blur planes i..i+3: DoG planes i..i+2
             if (lane == 0) q_n[wv] = 0;
             float v[DET_ROWS][4];
 #pragma unroll
@@ -793,15 +863,17 @@ __global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ a
                 const int y = y0 + r;
                 const bool ok = lane_ok && y > 8 && y < h - 8; // cudaSiftD.cu:289-290
                 if ((y & 31) < 30) { // wave-uniform
-                    const float4 t = *reinterpret_cast<const float4 *>(d3 + plane + (ok ? x4 + (long)p * y : 0));
-                    v[r][0] = t.x;
-                    v[r][1] = t.y;
-                    v[r][2] = t.z;
-                    v[r][3] = t.w;
+                    const float *c = b3 + plane + (ok ? x4 + (long)p * y : 0);
+                    const float4 t = *reinterpret_cast<const float4 *>(c);
+                    const float4 u = *reinterpret_cast<const float4 *>(c + plane);
+                    v[r][0] = __fsub_rn(t.x, u.x);
+                    v[r][1] = __fsub_rn(t.y, u.y);
+                    v[r][2] = __fsub_rn(t.z, u.z);
+                    v[r][3] = __fsub_rn(t.w, u.w);
                 } else { // the centre value itself is read through an aliased cell
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        v[r][q] = center_value(d3, plane, w, p, h, ok ? min(x4 + q, w - 1) : 0, ok ? y : 0);
+                        v[r][q] = center_value(b3, plane, w, p, h, ok ? min(x4 + q, w - 1) : 0, ok ? y : 0);
                 }
             }
             __syncthreads();
@@ -824,8 +896,8 @@ __global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ a
                 unsigned xy = 0;
                 if (e < nq) {
                     xy = q_xy[wv][e];
-                    hit = accept_candidate(d3, blur + i * plane, plane, w, p, h, a.edge_limit,
-                                           (int)(xy & 0xffffu), (int)(xy >> 16));
+                    hit = accept_candidate<false>(b3, plane, w, p, h, a.edge_limit, (int)(xy & 0xffffu),
+                                           (int)(xy >> 16));
                 }
                 append_hits(hit, xy, lane, &counts[g], cand + (long)g * a.cap, a.cap);
             }
@@ -977,7 +1049,7 @@ __global__ __launch_bounds__(64) void keypoint_kernel(
         const unsigned xy = cand[(long)g * cap + local];
         const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
         const int w = oc.w, h = oc.h, p = oc.p;
-        const float *bl = arena + oc.blur_off + (long)si * p * h; // blur plane si+1
+        const float *bl = arena + oc.blur_off + (long)(si + 1) * p * h; // blur plane si+1
 
         __syncthreads(); // previous keypoint's readers are done with the LDS arrays
         {
@@ -1408,17 +1480,17 @@ int hl_col_blur_dog(const float *tmp, long tmp_stride, float *blur, long blur_st
 }
 
 int hl_pyramid(const float *src, int src_w, int src_h, int src_pitch, long src_stride, int subsample,
-               float *blur, long blur_stride, float *dog, long dog_stride, int w, int p, int h,
+               float *blur, long blur_stride, int w, int p, int h,
                int n_scales, int nimg, const hl_taps *taps, float contrast, unsigned *queue,
                long queue_stride, unsigned *qcount, long qcount_stride, int qcap, int group0,
                void *stream)
 {
-    if (w <= 0 || h <= 0 || nimg <= 0 || !src || !blur || !dog || src_pitch < src_w) return -1001;
+    if (w <= 0 || h <= 0 || nimg <= 0 || !src || !blur || src_pitch < src_w) return -1001;
     if (p < w || (p & 63)) return -1005; // all 64 lanes of a block store: the pitch must cover them
     if (subsample ? (w != (src_w + 1) / 2 || h != (src_h + 1) / 2) : (w != src_w || h != src_h))
         return -1006;
-    // 32-bit byte offsets inside one image's source, blur and DoG planes
-    if ((long)p * h * (n_scales + 2) * 4 >= (long)FZ_DROP || (long)src_pitch * src_h * 4 > 0xffffffffL)
+    // 32-bit byte offsets inside one image's source and blur planes
+    if ((long)p * h * (n_scales + 3) * 4 >= (long)FZ_DROP || (long)src_pitch * src_h * 4 > 0xffffffffL)
         return -1007;
     if (queue && (!qcount || qcap < 1 || w > 65535 || h > 65535)) return -1008;
     // strip height 20*m - 18: every strip recomputes an 18-row apron, so strips are as
@@ -1437,7 +1509,7 @@ int hl_pyramid(const float *src, int src_w, int src_h, int src_pitch, long src_s
     ScopedTimer t(4, s);
 #define PYR_LAUNCH(SS, MD)                                                                         \
     hipLaunchKernelGGL((pyramid_kernel<SS, MD>), grid, block, 0, s, src, src_w, src_h, src_pitch,  \
-                       src_stride, blur, blur_stride, dog, dog_stride, w, p, h, rows, *taps,       \
+                       src_stride, blur, blur_stride, w, p, h, rows, *taps,                        \
                        contrast, queue, queue_stride, qcount, qcount_stride, qcap, group0)
     if (n_scales == 2 && !subsample)
         PYR_LAUNCH(2, 0);
@@ -1460,7 +1532,7 @@ static int detect_args_ok(const hl_detect_args *a, int nimg)
     for (int o = 0; o < a->n_oct; ++o) {
         const hl_octave *c = &a->oct[o];
         if (c->w < 1 || c->h < 1 || c->p < c->w || (c->p & 3) || c->w > 65535 || c->h > 65535) return 0;
-        if ((c->dog_off & 3) || c->qcap < 1) return 0;
+        if ((c->blur_off & 3) || c->qcap < 1) return 0;
     }
     return 1;
 }
