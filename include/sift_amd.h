@@ -98,7 +98,7 @@ void sift_shutdown(void);
 int sift_extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
                        const float *d_imgs, long img_stride, int n,
                        int width, int pitch, int height, void *stream);
-/* images worked on per launch set (default 64); arenas grow to match */
+/* images worked on per launch set (default 256); arenas grow to match */
 void sift_set_batch_chunk(int images_per_launch);
 /* Detection is sparse: the pyramid pass queues the pixels that pass the contrast
  * test and only those are examined further.  n = first-octave queue capacity per

@@ -60,7 +60,7 @@ static unsigned *g_batch_count[MAX_DEV];
 static int g_batch_count_n[MAX_DEV];
 static int g_lanes = N_LANES;
 static unsigned *g_slot_counter[MAX_DEV]; /* device, SIFT_MAX_SLOTS words */
-static int g_chunk = 64;
+static int g_chunk = 256;
 static int g_queue_cap = QUEUE_CAP; /* 0: no pre-filter, dense detector only */
 static char g_err[512] = "";
 

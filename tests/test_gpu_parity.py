@@ -161,7 +161,7 @@ def test_batch_entry_matches_per_image_oracle(sift, oracle_mod):
     ref_pts, ref_counts = oracle_mod.extract_batch(pr, imgs, w, n_threads=8)
     sift.lib().sift_set_batch_chunk(4)  # 3 launch sets: 4 + 4 + 3
     d_pts, counts, meta = sift.extract_batch(torch.from_numpy(imgs).cuda(), w, want_meta=True)
-    sift.lib().sift_set_batch_chunk(8)
+    sift.lib().sift_set_batch_chunk(256)
     assert counts.tolist() == ref_counts.tolist() and counts.sum() > 100
     meta = meta.cpu().numpy().reshape(n, pr.max_points, 2)
     for i in range(n):

@@ -11,8 +11,8 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ("pyramid", "row_blur", "col_blur_dog", "detect", "keypoint", "finalize", "fillBuffer", "copyBuffer",
-              "subtract", "hessian", "gradient"):
+    for k in ("pyramid", "row_blur", "col_blur_dog", "alias_prefilter", "verify", "detect", "keypoint", "finalize",
+              "fillBuffer", "copyBuffer", "subtract", "hessian", "gradient"):
         if k in name:
             return k
     return name[:40]
@@ -29,7 +29,10 @@ def main(root):
     dur = {}
     for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            dur[short(row["Name"])] = (float(row["AverageNs"]), int(row["Calls"]))
+            k = short(row["Name"])  # template instantiations of one kernel are pooled
+            ns, calls = dur.get(k, (0.0, 0))
+            n = int(row["Calls"])
+            dur[k] = ((ns * calls + float(row["AverageNs"]) * n) / (calls + n), calls + n)
     for k in sorted(acc):
         print(f"== {k}")
         c = {n: v[0] / max(v[1], 1) for n, v in acc[k].items()}
@@ -48,6 +51,19 @@ def main(root):
                 print(f"   L2 hit rate {c['TCC_HIT_sum']/t:.3f}")
         if "SQ_LDS_IDX_ACTIVE" in c and c["SQ_LDS_IDX_ACTIVE"]:
             print(f"   LDS bank-conflict cycles / LDS active cycles = {c.get('SQ_LDS_BANK_CONFLICT',0)/c['SQ_LDS_IDX_ACTIVE']:.4f}")
+
+
+    # HBM-side bytes per launch of the pyramid kernel, in the form bench.py reads
+    if len(sys.argv) > 3 and "pyramid" in acc and "FETCH_SIZE" in acc["pyramid"] and "WRITE_SIZE" in acc["pyramid"]:
+        import json
+
+        c = {n: v[0] / max(v[1], 1) for n, v in acc["pyramid"].items()}
+        rd, wr = c["FETCH_SIZE"] * 1024 * 2, c["WRITE_SIZE"] * 1024
+        json.dump({"pyramid_kernel": {"batch": int(sys.argv[3]), "hbm_bytes_per_launch": rd + wr,
+                                      "read_bytes": rd, "write_bytes": wr,
+                                      "source": "rocprofv3 --pmc FETCH_SIZE (x2, calibrated on dword-per-lane reads of a "
+                                                "known size) and WRITE_SIZE, separate passes, mean over launches"}},
+                  open(sys.argv[2], "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -16,6 +16,23 @@ __global__ __launch_bounds__(64) void strips(float *out, const float *in, int p,
     const float *s = in + blockIdx.z * (long)p * h;
     const long plane = (long)p * h;
     float v = (float)lane;
+    if (NT & 4) { // source rows fetched four rows ahead, as the pyramid kernel does
+        float g[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = s[(long)min(y0 + q, h - 1) * p + x];
+        for (int y = y0; y < y1; y += 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v += g[q];
+                g[q] = s[(long)min(y + q + 4, h - 1) * p + x];
+                if (y + q < y1) {
+#pragma unroll
+                    for (int i = 0; i < NPL; ++i) o[i * plane + (long)(y + q) * p + x] = v + i;
+                }
+            }
+        }
+        return;
+    }
     for (int y = y0; y < y1; ++y) {
         if (READ) v += (NT & 2) ? __builtin_nontemporal_load(&s[(long)y * p + x]) : s[(long)y * p + x];
 #pragma unroll
@@ -56,8 +73,8 @@ int main()
                 case 1: hipLaunchKernelGGL((strips<NPL, true, 0>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride); break;
                 case 2: hipLaunchKernelGGL((strips<NPL, false, 1>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride); break;
                 case 3: hipLaunchKernelGGL((strips<NPL, true, 1>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride); break;
-                case 4: hipLaunchKernelGGL((strips<NPL, true, 2>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride); break;
-                case 5: hipLaunchKernelGGL((strips<NPL, true, 3>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride); break;
+                case 4: hipLaunchKernelGGL((strips<5, true, 4>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride); break;
+                case 5: hipLaunchKernelGGL((strips<NPL, true, 4>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride); break;
                 case 6: hipLaunchKernelGGL((strips<5, true, 0>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride); break;
                 case 7: hipLaunchKernelGGL((strips<4, true, 0>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride); break;
                 }
@@ -67,8 +84,8 @@ int main()
                 hipEventElapsedTime(&ms, e0, e1);
                 if (it && ms < best) best = ms;
             }
-            static const char *nm[] = {"6pl store", "6pl store+load", "6pl nt-store", "6pl nt-store+load", "6pl store+nt-load", "6pl nt-store+nt-load", "5pl store+load", "4pl store+load"};
-            const double by = bytes * (rd == 6 ? 5.0 / 6 : rd == 7 ? 4.0 / 6 : 1.0);
+            static const char *nm[] = {"6pl store", "6pl store+load", "6pl nt-store", "6pl nt-store+load", "5pl store+prefetched load", "6pl store+prefetched load", "5pl store+load", "4pl store+load"};
+            const double by = bytes * ((rd == 6 || rd == 4) ? 5.0 / 6 : rd == 7 ? 4.0 / 6 : 1.0);
             printf("%-22s rows=%d: %.3f ms  write %.2f TB/s\n", nm[rd], rows, best, by / best / 1e9);
         }
     }
