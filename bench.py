@@ -42,13 +42,13 @@ def algorithmic_bytes(s):
     `pyramid`: what the fused row+column kernel has to move: read the octave's
     source once, write the S+3 blur planes (DoG values are formed by their
     readers; the next octave reads blur plane S in place).
-    `two_pass`: the same work as two kernels with the S+3 row-blurred planes
-    written to and re-read from HBM and DoG planes stored (the accounting of a
-    separable two-pass design), kept for comparison.
+    `two_pass`: the same work as a separable two-pass design with stored DoG
+    planes and a materialised next-octave base: row pass R 1 + W (S+3), column
+    pass R (S+3) + W S + W (S+2), down-sample R 1/4 + W 1/4; kept for comparison.
     `detect`: the dense detector reads the S+3 blur planes."""
     return {
         "pyramid": (1 + (s + 3)) * 4.0,
-        "two_pass": (1 + (s + 3)) * 4.0 + ((s + 3) + s + (s + 2) + 0.25) * 4.0,
+        "two_pass": (4 * s + 9.5) * 4.0,
         "detect": (s + 3) * 4.0,
     }
 
@@ -91,12 +91,24 @@ def main():
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torchrun", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
+    # BENCH_ONE_DEVICE=1 puts every rank on device 0: a rehearsal of the N > 1 path on a one-GPU box
+    torch.cuda.set_device(0 if os.environ.get("BENCH_ONE_DEVICE") else local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # the data path has no collective; only the timing and the keypoint count are reduced,
+        # as host scalars, so the rendezvous runs over gloo
+        # (its transport announces itself on stdout, which must carry the JSON line only)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
 
     sift_amd.lib()  # raises if the HIP library is missing
     sift_amd.set_params(n_octaves=O, n_scales=S, max_points=CAP)
@@ -132,10 +144,10 @@ def main():
     elapsed = time.perf_counter() - t0
     sift_amd.timing_enable(False)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        k = torch.tensor([float(counts.sum())], dtype=torch.float64, device="cuda")
+        k = torch.tensor([float(counts.sum())], dtype=torch.float64)
         dist.all_reduce(k, op=dist.ReduceOp.SUM)
         keypoints_per_step = float(k.item())
     else:
@@ -199,7 +211,7 @@ def main():
         if dom == "pyramid":
             out["roofline"]["two_pass_equivalent_GBps"] = achieved / 1e9 * ab["two_pass"] / ab["pyramid"]
             out["roofline"]["note"] = ("fused row+column pass: 24 B/px moved (a two-pass design with stored DoG "
-                                       "planes moves 69 B/px) beside 190 FP32 FMA/px")
+                                       "planes moves 70 B/px) beside 190 FP32 FMA/px")
         out["kernels_ms_per_image"] = {k: v["ms_total"] / (args.batch * args.steps) for k, v in kern.items()}
         # HBM-side bytes per launch of the dominant kernel from rocprofv3 counters (separate
         # FETCH_SIZE / WRITE_SIZE passes over this same command, tools/prof_pmc.sh), if committed
