@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--dense", action="store_true", help="high keypoint density images")
     ap.add_argument("--queue-cap", type=int, default=-1,
                     help="candidate queue entries per image and scale (0 = dense detector only; -1 = library default)")
+    ap.add_argument("--u8", action="store_true", help="8-bit images in HBM, converted by the pyramid kernel's fetch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=48)
     args = ap.parse_args()
@@ -121,7 +122,7 @@ def main():
 
     threads = min(16, os.cpu_count() or 1)
     host = gen_images(args.batch, SEED0 + rank * args.batch, args.dense, threads)
-    d_imgs = torch.from_numpy(host).cuda()
+    d_imgs = torch.from_numpy(host.astype(np.uint8) if args.u8 else host).cuda()  # the images hold integers
     d_pts = torch.empty((args.batch * CAP, sift_amd.POINT_FLOATS), dtype=torch.float32, device="cuda")
 
     def barrier():
@@ -170,7 +171,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.batch} synthetic {W}x{H} f32 images per GPU, {S} scales, {O} octaves, "
+            "workload": f"{args.batch} synthetic {W}x{H} {'u8' if args.u8 else 'f32'} images per GPU, {S} scales, {O} octaves, "
                         f"cap {CAP}, semantics profile ref, inputs resident in HBM"
                         + (", dense blobs" if args.dense else ""),
             "parallelism": f"dp{world} (independent image batches, no collective)",

@@ -98,6 +98,13 @@ void sift_shutdown(void);
 int sift_extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
                        const float *d_imgs, long img_stride, int n,
                        int width, int pitch, int height, void *stream);
+/* The same for 8-bit grey images, the form images have on disk and on the wire:
+ * a pixel is converted to float (image::imload's convertTo(CV_32F), utils.cc:13)
+ * as the pyramid kernel fetches it, so results equal those of the float entry on
+ * the converted image.  img_stride and pitch count bytes. */
+int sift_extract_batch_u8(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
+                          const unsigned char *d_imgs, long img_stride, int n,
+                          int width, int pitch, int height, void *stream);
 /* images worked on per launch set (default 256); arenas grow to match */
 void sift_set_batch_chunk(int images_per_launch);
 /* Detection is sparse: the pyramid pass queues the pixels that pass the contrast

@@ -61,6 +61,7 @@ SYMBOLS = {
     "sift_get_tables": (None, [_fp, _fp, _fp]),
     "sift_shutdown": (None, []),
     "sift_extract_batch": (C.c_int, [_vp, _vp, _ip, _vp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "sift_extract_batch_u8": (C.c_int, [_vp, _vp, _ip, _vp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "sift_set_batch_chunk": (None, [C.c_int]),
     "sift_set_batch_lanes": (None, [C.c_int]),
     "sift_set_queue_cap": (None, [C.c_int]),
@@ -270,20 +271,24 @@ def computeGradient(blur, width, stream=None):
 
 
 def extract_batch(d_imgs, width, want_meta=False, stream=None, d_pts=None):
-    """d_imgs: (n, height, pitch) float32 CUDA tensor.  Returns (point tensor, counts[, meta])."""
+    """d_imgs: (n, height, pitch) CUDA tensor, float32 or uint8 (8-bit grey, converted on the
+    fly).  Returns (point tensor, counts[, meta])."""
     import torch
 
     if d_imgs.dim() != 3:
         raise SiftError("expected (n, height, pitch)")
+    if d_imgs.dtype not in (torch.float32, torch.uint8) or not d_imgs.is_cuda or not d_imgs.is_contiguous():
+        raise SiftError("expected a contiguous float32 or uint8 CUDA tensor")
     n, h, p = d_imgs.shape
     cap = get_params().max_points
     if d_pts is None:
         d_pts = torch.empty((n * cap, POINT_FLOATS), dtype=torch.float32, device=d_imgs.device)
     meta = torch.zeros((n * cap, 2), dtype=torch.uint8, device=d_imgs.device) if want_meta else None
     counts = np.zeros(n, np.int32)
-    rc = lib().sift_extract_batch(
-        _dev_f32(d_pts), C.c_void_p(meta.data_ptr()) if want_meta else None,
-        counts.ctypes.data_as(_ip), _dev_f32(d_imgs), h * p, n, width, p, h, _stream_ptr(stream))
+    entry = lib().sift_extract_batch_u8 if d_imgs.dtype == torch.uint8 else lib().sift_extract_batch
+    rc = entry(_dev_f32(d_pts), C.c_void_p(meta.data_ptr()) if want_meta else None,
+               counts.ctypes.data_as(_ip), C.c_void_p(d_imgs.data_ptr()), h * p, n, width, p, h,
+               _stream_ptr(stream))
     _ok(rc)
     return (d_pts, counts, meta) if want_meta else (d_pts, counts)
 

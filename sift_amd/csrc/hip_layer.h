@@ -93,15 +93,17 @@ int hl_col_blur_dog(const float *tmp, long tmp_stride, float *blur, long blur_st
                     long next_stride, int next_p, int w, int p, int h, int n_scales, int nimg,
                     const hl_taps *taps, void *stream);
 /* fused row pass + column pass: source -> the S+3 blur planes, no intermediate
- * in HBM (DoG plane i is blur plane i minus blur plane i+1, formed by its readers).  subsample != 0: the source is the previous octave's
- * blur plane S (src_w x src_h) and is read at its even rows and columns, so
- * w = ceil(src_w/2), h = ceil(src_h/2).  p must be a multiple of 64: columns
- * [w, p) of the destination planes are written with don't-care values.
+ * in HBM (DoG plane i is blur plane i minus blur plane i+1, formed by its readers).
+ * src_mode 0: float image.  1: 8-bit image (src points at bytes, src_pitch and
+ * src_stride count bytes).  2: the source is the previous octave's blur plane S
+ * (src_w x src_h) and is read at its even rows and columns, so w = ceil(src_w/2),
+ * h = ceil(src_h/2).  p must be a multiple of 64: columns [w, p) of the
+ * destination planes are written with don't-care values.
  * queue != NULL: pixels passing the detector's contrast and border tests (rows
  * with y mod 32 >= 30 excepted) are queued per scale: entry (x | y<<16) at
  * queue[i*qcap + k], count in qcount[group0 + i]; a count above qcap means the
  * queue is incomplete and the dense detector must redo that scale. */
-int hl_pyramid(const float *src, int src_w, int src_h, int src_pitch, long src_stride, int subsample,
+int hl_pyramid(const void *src, int src_w, int src_h, int src_pitch, long src_stride, int src_mode,
                float *blur, long blur_stride, int w, int p, int h,
                int n_scales, int nimg, const hl_taps *taps, float contrast, unsigned *queue,
                long queue_stride, unsigned *qcount, long qcount_stride, int qcap, int group0,

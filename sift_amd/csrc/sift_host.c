@@ -322,9 +322,9 @@ static int ensure_arena(slot_ctx *c, int w, int h, int oct0, int nimg)
  * cudaSiftH.cu:9-117 does this per image with a recursion, 12 allocations and
  * a dozen blocking copies per octave; here the octaves are a loop over a
  * preplanned arena and nothing blocks. */
-static int enqueue_extract(slot_ctx *c, SiftPoint *pts, unsigned char *meta, const float *imgs,
-                           long img_stride, int nimg, int pitch, int oct0, unsigned *base_count,
-                           void *stream)
+static int enqueue_extract(slot_ctx *c, SiftPoint *pts, unsigned char *meta, const void *imgs,
+                           int imgs_u8, long img_stride, int nimg, int pitch, int oct0,
+                           unsigned *base_count, void *stream)
 {
     const int S = g_params.n_scales, O = g_params.n_octaves, cap = g_params.max_points;
     int r = hl_memset_async(c->counts, 0, sizeof(unsigned) * COUNT_WORDS * nimg, stream);
@@ -352,13 +352,13 @@ static int enqueue_extract(slot_ctx *c, SiftPoint *pts, unsigned char *meta, con
         da.band0[oi + 1] = da.band0[oi] + idivup(hh, 32);
         da.dense0[oi + 1] = da.dense0[oi] + idivup(ww, 256) * idivup(hh, 32);
         if (o == oct0)
-            r = hl_pyramid(imgs, ww, hh, pitch, img_stride, 0, A + c->blur_off[oi], AS,
+            r = hl_pyramid(imgs, ww, hh, pitch, img_stride, imgs_u8 ? 1 : 0, A + c->blur_off[oi], AS,
                            ww, pp, hh, S, nimg, &g_taps, da.contrast,
                            prefilter ? c->queue + c->queue_off[oi] : NULL, c->queue_stride, queued,
                            COUNT_WORDS, c->qcap[oi], oi * S, stream);
         else /* cudaSiftH.cu:50-52: the next octave is the even pixels of blur plane S */
             r = hl_pyramid(A + c->blur_off[oi - 1] + (long)S * c->op[oi - 1] * c->oh[oi - 1],
-                           c->ow[oi - 1], c->oh[oi - 1], c->op[oi - 1], AS, 1, A + c->blur_off[oi],
+                           c->ow[oi - 1], c->oh[oi - 1], c->op[oi - 1], AS, 2, A + c->blur_off[oi],
                            AS, ww, pp, hh, S, nimg, &g_taps, da.contrast,
                            prefilter ? c->queue + c->queue_off[oi] : NULL, c->queue_stride, queued,
                            COUNT_WORDS, c->qcap[oi], oi * S, stream);
@@ -460,7 +460,7 @@ void extractSift(SiftPoint *siftPt, float *d_src, int width, int pitch, int heig
         slot_ctx *c = &g_slots[dev][streamIdx];
         if (ensure_arena(c, width, height, octaveIdx, 1))
             break;
-        enqueue_extract(c, siftPt, NULL, d_src, 0, 1, pitch, octaveIdx,
+        enqueue_extract(c, siftPt, NULL, d_src, 0, 0, 1, pitch, octaveIdx,
                         g_slot_counter[dev] + streamIdx, stream);
     } while (0);
     pthread_mutex_unlock(&g_mu);
@@ -520,9 +520,11 @@ void sift_set_batch_lanes(int n)
         g_lanes = n;
 }
 
-int sift_extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts, const float *d_imgs,
-                       long img_stride, int n, int width, int pitch, int height, void *stream)
+static int extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts, const void *d_imgs,
+                         int imgs_u8, long img_stride, int n, int width, int pitch, int height,
+                         void *stream)
 {
+    const long esz = imgs_u8 ? 1 : (long)sizeof(float);
     int rc = -1;
     pthread_mutex_lock(&g_mu);
     do {
@@ -585,8 +587,8 @@ int sift_extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts, c
             const int l = k % lanes;
             bad = enqueue_extract(&g_slots[dev][BATCH_SLOT + l], d_pts + (long)i0 * cap,
                                   d_meta ? d_meta + 2L * i0 * cap : NULL,
-                                  d_imgs + (long)i0 * img_stride, img_stride, m, pitch, 0, bc + i0,
-                                  g_lane_stream[dev][l]);
+                                  (const char *)d_imgs + (long)i0 * img_stride * esz, imgs_u8,
+                                  img_stride, m, pitch, 0, bc + i0, g_lane_stream[dev][l]);
         }
         /* join: the caller's stream continues after both private streams */
         for (int l = 0; l < lanes; ++l) {
@@ -606,6 +608,19 @@ int sift_extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts, c
     } while (0);
     pthread_mutex_unlock(&g_mu);
     return rc;
+}
+
+int sift_extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts, const float *d_imgs,
+                       long img_stride, int n, int width, int pitch, int height, void *stream)
+{
+    return extract_batch(d_pts, d_meta, h_counts, d_imgs, 0, img_stride, n, width, pitch, height, stream);
+}
+
+int sift_extract_batch_u8(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
+                          const unsigned char *d_imgs, long img_stride, int n, int width, int pitch,
+                          int height, void *stream)
+{
+    return extract_batch(d_pts, d_meta, h_counts, d_imgs, 1, img_stride, n, width, pitch, height, stream);
 }
 
 /* ---- stage launchers (dense planes, reference layout) ------------------------ */

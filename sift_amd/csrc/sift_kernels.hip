@@ -251,7 +251,9 @@ __global__ __launch_bounds__(64) void col_blur_dog_kernel(
 // has two slots so the write of row r+1 is issued a whole step before its
 // first read.
 //
-// SRC_MODE 0: source is an image (any pitch or alignment)
+// SRC_MODE 0: source is a float image (any pitch or alignment)
+//          1: source is an 8-bit image (src points at bytes; pitch and stride in
+//             bytes); a pixel becomes the float of the same value when staged
 //          2: source is the previous octave's blur plane S, read at even rows
 //             and even columns (resizeKernel cudaSiftD.cu:544-559 folded into
 //             the fetch; the down-sampled base is never materialised)
@@ -306,12 +308,13 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     const int nin = (y1 - y0) + 2 * RADIUS;
     const long plane = (long)p * h;
     const int z = tile_z;
-    src += z * src_stride;
+    constexpr int ES = SRC_MODE == 1 ? 1 : 4; // bytes per source element
     // buffer descriptors (wave-uniform): 32-bit per-lane offsets in one VGPR and
     // per-row / per-plane offsets in scalar registers replace 64-bit per-lane
     // address arithmetic
     const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(src), 0, (int)(unsigned)min((long)src_pitch * src_h * 4, 0xffffffffL), 0x00020000);
+        const_cast<char *>(reinterpret_cast<const char *>(src) + z * src_stride * ES), 0,
+        (int)(unsigned)min((long)src_pitch * src_h * ES, 0xffffffffL), 0x00020000);
     const __amdgpu_buffer_rsrc_t bl_rs = __builtin_amdgcn_make_buffer_rsrc(
         blur + z * blur_stride, 0, (int)(unsigned)min(plane * NP * 4, (long)FZ_DROP), 0x00020000);
     // destination of the next completed output row; advanced row by row (a
@@ -342,8 +345,8 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     {
         const int xa = x0 - 12 + lane, xb = xa + 64;
         const bool oka = xa >= 0 && xa < w, okb = lane < FZ_STAGE - 64 && xb >= 0 && xb < w;
-        col_off[0] = oka ? SX * xa * 4 : 0;
-        col_off[1] = okb ? SX * xb * 4 : 0;
+        col_off[0] = oka ? SX * xa * ES : 0;
+        col_off[1] = okb ? SX * xb * ES : 0;
         col_mask[0] = oka ? 0xffffffffu : 0u;
         col_mask[1] = okb ? 0xffffffffu : 0u;
     }
@@ -355,16 +358,24 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     auto fetch = [&]() __attribute__((always_inline)) -> Row {
         const int yi = yi_next++;
         const int yc = min(max(yi, 0), h - 1);
-        const int row = (int)((unsigned)(SX * yc) * (unsigned)src_pitch * 4u);
+        const int row = (int)((unsigned)(SX * yc) * (unsigned)src_pitch * (unsigned)ES);
         Row o;
-        o.v.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src_rs, col_off[0], row, 0));
-        o.v.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src_rs, col_off[1], row, 0));
+        if (SRC_MODE == 1) { // the byte travels as an integer until it is staged
+            o.v.x = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b8(src_rs, col_off[0], row, 0));
+            o.v.y = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b8(src_rs, col_off[1], row, 0));
+        } else {
+            o.v.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src_rs, col_off[0], row, 0));
+            o.v.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src_rs, col_off[1], row, 0));
+        }
         o.ok = (yi >= 0 && yi < h) ? 0xffffffffu : 0u;
         return o;
     };
+    auto pixel = [](float raw) __attribute__((always_inline)) {
+        return SRC_MODE == 1 ? (float)(__float_as_uint(raw) & 0xffu) : raw;
+    };
     auto stage = [&](int slot, const Row &o) __attribute__((always_inline)) {
-        lds[slot][lane] = masked(o.v.x, col_mask[0] & o.ok);
-        lds[slot][lane + 64] = masked(o.v.y, col_mask[1] & o.ok); // lanes >= 24 write unused cells
+        lds[slot][lane] = masked(pixel(o.v.x), col_mask[0] & o.ok);
+        lds[slot][lane + 64] = masked(pixel(o.v.y), col_mask[1] & o.ok); // lanes >= 24 write unused cells
     };
 
     constexpr int NPAIR = NP / 2;
@@ -1479,7 +1490,7 @@ int hl_col_blur_dog(const float *tmp, long tmp_stride, float *blur, long blur_st
     return launch_status();
 }
 
-int hl_pyramid(const float *src, int src_w, int src_h, int src_pitch, long src_stride, int subsample,
+int hl_pyramid(const void *src, int src_w, int src_h, int src_pitch, long src_stride, int src_mode,
                float *blur, long blur_stride, int w, int p, int h,
                int n_scales, int nimg, const hl_taps *taps, float contrast, unsigned *queue,
                long queue_stride, unsigned *qcount, long qcount_stride, int qcap, int group0,
@@ -1487,10 +1498,11 @@ int hl_pyramid(const float *src, int src_w, int src_h, int src_pitch, long src_s
 {
     if (w <= 0 || h <= 0 || nimg <= 0 || !src || !blur || src_pitch < src_w) return -1001;
     if (p < w || (p & 63)) return -1005; // all 64 lanes of a block store: the pitch must cover them
-    if (subsample ? (w != (src_w + 1) / 2 || h != (src_h + 1) / 2) : (w != src_w || h != src_h))
+    if (src_mode < 0 || src_mode > 2) return -1002;
+    if (src_mode == 2 ? (w != (src_w + 1) / 2 || h != (src_h + 1) / 2) : (w != src_w || h != src_h))
         return -1006;
     // 32-bit byte offsets inside one image's source and blur planes
-    if ((long)p * h * (n_scales + 3) * 4 >= (long)FZ_DROP || (long)src_pitch * src_h * 4 > 0xffffffffL)
+    if ((long)p * h * (n_scales + 3) * 4 >= (long)FZ_DROP || (long)src_pitch * src_h * (src_mode == 1 ? 1 : 4) > 0xffffffffL)
         return -1007;
     if (queue && (!qcount || qcap < 1 || w > 65535 || h > 65535)) return -1008;
     // strip height 20*m - 18: every strip recomputes an 18-row apron, so strips are as
@@ -1508,19 +1520,18 @@ int hl_pyramid(const float *src, int src_w, int src_h, int src_pitch, long src_s
     hipStream_t s = (hipStream_t)stream;
     ScopedTimer t(4, s);
 #define PYR_LAUNCH(SS, MD)                                                                         \
-    hipLaunchKernelGGL((pyramid_kernel<SS, MD>), grid, block, 0, s, src, src_w, src_h, src_pitch,  \
-                       src_stride, blur, blur_stride, w, p, h, rows, *taps,                        \
+    hipLaunchKernelGGL((pyramid_kernel<SS, MD>), grid, block, 0, s, (const float *)src, src_w,     \
+                       src_h, src_pitch, src_stride, blur, blur_stride, w, p, h, rows, *taps,      \
                        contrast, queue, queue_stride, qcount, qcount_stride, qcap, group0)
-    if (n_scales == 2 && !subsample)
-        PYR_LAUNCH(2, 0);
-    else if (n_scales == 2)
-        PYR_LAUNCH(2, 2);
-    else if (n_scales == 3 && !subsample)
-        PYR_LAUNCH(3, 0);
-    else if (n_scales == 3)
-        PYR_LAUNCH(3, 2);
-    else
-        return -1002;
+    if (n_scales != 2 && n_scales != 3) return -1002;
+    switch (src_mode + 3 * (n_scales - 2)) {
+    case 0: PYR_LAUNCH(2, 0); break;
+    case 1: PYR_LAUNCH(2, 1); break;
+    case 2: PYR_LAUNCH(2, 2); break;
+    case 3: PYR_LAUNCH(3, 0); break;
+    case 4: PYR_LAUNCH(3, 1); break;
+    default: PYR_LAUNCH(3, 2); break;
+    }
 #undef PYR_LAUNCH
     return launch_status();
 }

@@ -265,3 +265,23 @@ def test_sparse_and_dense_detectors_agree_on_random_shapes(sift, oracle_mod):
         assert len(dense) == len(sparse), (case, w, h, S, thr, len(dense), len(sparse))
         assert oracle_mod.sort_points(dense).tobytes() == oracle_mod.sort_points(sparse).tobytes(), (case, w, h, S, thr)
     assert len(dense) > 0
+
+
+def test_u8_batch_entry_equals_float_entry(sift, oracle_mod):
+    """8-bit images converted by the pyramid kernel's fetch: same bytes out as the float entry on
+    the converted images, which the oracle pins; odd width and a pitch that is not a multiple of 4."""
+    pr = _params(sift, oracle_mod, n_scales=2, n_octaves=4, max_points=4000)
+    n, w, h, pitch = 5, 333, 250, 335
+    imgs = np.stack([sift.synth_image(w, h, seed=500 + i, dense=True) for i in range(n)])
+    assert np.array_equal(imgs, np.round(imgs)) and imgs.min() >= 0 and imgs.max() <= 255
+    u8 = np.zeros((n, h, pitch), np.uint8)
+    u8[:, :, :w] = imgs.astype(np.uint8)
+    pts8, counts8 = sift.extract_batch(torch.from_numpy(u8).cuda(), w)
+    ptsf, countsf = sift.extract_batch(torch.from_numpy(imgs).cuda(), w)
+    assert counts8.tolist() == countsf.tolist() and counts8.sum() > 200
+    ref, _, _ = oracle_mod.extract(pr, imgs[0], w)
+    _assert_points_equal(oracle_mod, sift.points_to_numpy(pts8, int(counts8[0])), ref)
+    for i in range(n):
+        a = sift.points_to_numpy(pts8, int(counts8[i]), offset=i * pr.max_points)
+        b = sift.points_to_numpy(ptsf, int(countsf[i]), offset=i * pr.max_points)
+        assert oracle_mod.sort_points(a).tobytes() == oracle_mod.sort_points(b).tobytes()
