@@ -285,3 +285,46 @@ def test_u8_batch_entry_equals_float_entry(sift, oracle_mod):
         a = sift.points_to_numpy(pts8, int(counts8[i]), offset=i * pr.max_points)
         b = sift.points_to_numpy(ptsf, int(countsf[i]), offset=i * pr.max_points)
         assert oracle_mod.sort_points(a).tobytes() == oracle_mod.sort_points(b).tobytes()
+
+
+def test_host_pipeline_writes_the_oracles_text_files(sift, oracle_mod, tmp_path):
+    """sift() (the counterpart of Sift/src/sift.cu:64-143): PGM/PPM files in, one .sift.txt per
+    image out, images taken two at a time on two streams.  Lines are compared as sets (the order
+    inside an (octave, scale) group is an atomic's) against the oracle's formatted points."""
+    import ctypes as C
+    from pnm import write_pnm
+
+    pr = _params(sift, oracle_mod, n_scales=2, n_octaves=4, max_points=2500)
+    src = tmp_path / "src"
+    dst = tmp_path / "dst"
+    src.mkdir()
+    dst.mkdir()
+    paths, grays = [], []
+    for i, (w, h) in enumerate([(320, 200), (257, 131), (400, 300)]):
+        img = sift.synth_image(w, h, seed=700 + i, dense=True).astype(np.uint8)
+        if i == 2:  # a colour file: the loader's Q14 grey conversion is part of the pipeline
+            rgb = np.stack([img, np.roll(img, 3, axis=1), np.roll(img, 5, axis=0)], axis=-1)
+            p = src / f"img{i}.ppm"
+            write_pnm(str(p), rgb)
+            grays.append(oracle_mod.gray_q14(rgb).astype(np.float32))
+        else:
+            p = src / f"img{i}.pgm"
+            write_pnm(str(p), img)
+            grays.append(img.astype(np.float32))
+        paths.append(str(p))
+    arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+    for drop in (0, 1):
+        sift.lib().sift_pipeline_drop_last_point(drop)
+        try:
+            assert sift.lib().sift(os.fsencode(str(dst)), arr, len(paths)) == 0, sift.last_error()
+        finally:
+            sift.lib().sift_pipeline_drop_last_point(0)
+        for p, g in zip(paths, grays):
+            ref, _, total = oracle_mod.extract(pr, g, g.shape[1])
+            assert total == len(ref) > 10
+            want = oracle_mod.format_points(ref).splitlines()
+            got = open(dst / (os.path.basename(p) + ".sift.txt")).read().splitlines()
+            if drop:  # the reference hands its writer count - 1 (sift.cu:125)
+                assert len(got) == len(want) - 1 and set(got) <= set(want)
+            else:
+                assert sorted(got) == sorted(want)
