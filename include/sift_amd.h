@@ -37,7 +37,21 @@ typedef struct {
     float sigma;          /* SIGMA          1.6f  utils.h:14 */
     float r_thresh;       /* R_THRESH       10.0f utils.h:16 */
     float extrema_thresh; /* EXTREMA_THRESH 10.0f utils.h:18 */
+    int profile;          /* SIFT_PROFILE_REF (default) or SIFT_PROFILE_LOWE */
+    int upsample;         /* profile lowe: put an octave built from the 2x up-sampled image in front */
 } sift_params;
+
+/* Semantics profiles.
+ * REF: the reference's behaviour, quirks of its detector included; positions are
+ *   integers in the grid of their octave (cudaSiftD.cu:299-300).
+ * LOWE: what the reference lacks (no counterpart in Sift/src): strict 26-neighbour
+ *   extrema of the same DoG pyramid, 3-D quadratic refinement of position and
+ *   scale, contrast test |D(refined)|*S >= extrema_thresh, edge test on the DoG
+ *   Hessian with det = Dxx*Dyy - Dxy^2; xpos, ypos in pixels of the input image,
+ *   scale = sigma * 2^(octave + (scale index + offset)/S).  Orientation and
+ *   descriptor are taken as in REF, at the sample the refinement ended on. */
+#define SIFT_PROFILE_REF 0
+#define SIFT_PROFILE_LOWE 1
 
 #define SIFT_MAX_OCTAVES 8
 #define SIFT_MAX_SLOTS 8 /* the reference has 2: d_PointCount[2], cudaSiftD.h:24-25 */
@@ -105,6 +119,11 @@ int sift_extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
 int sift_extract_batch_u8(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
                           const unsigned char *d_imgs, long img_stride, int n,
                           int width, int pitch, int height, void *stream);
+/* 8-bit descriptors (no counterpart in the reference, whose descriptors are
+ * float and L1-normalised, cudaSiftD.cu:186-200): d_out[128*j + k] =
+ * min(255, round(512 * d_pts[j].data[k])) for the first n points.  Asynchronous
+ * on `stream`.  Returns 0 or a negative error. */
+int sift_quantize_descriptors(const SiftPoint *d_pts, int n, unsigned char *d_out, void *stream);
 /* images worked on per launch set (default 256); arenas grow to match */
 void sift_set_batch_chunk(int images_per_launch);
 /* Detection is sparse: the pyramid pass queues the pixels that pass the contrast

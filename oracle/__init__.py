@@ -26,6 +26,8 @@ class Params(C.Structure):
         ("sigma", C.c_float),
         ("r_thresh", C.c_float),
         ("extrema_thresh", C.c_float),
+        ("profile", C.c_int),
+        ("upsample", C.c_int),
     ]
 
 
@@ -73,6 +75,12 @@ def lib():
         L.oracle_gray_q14.restype = None
         L.oracle_format_points.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_long]
         L.oracle_format_points.restype = C.c_long
+        L.oracle_det_exp2.argtypes = [C.c_double]
+        L.oracle_det_exp2.restype = C.c_double
+        L.oracle_upsample2x.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp]
+        L.oracle_upsample2x.restype = None
+        L.oracle_quantize_descriptors.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.oracle_quantize_descriptors.restype = None
         _lib = L
     return _lib
 
@@ -81,8 +89,9 @@ def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
-def params(n_octaves=4, n_scales=2, max_points=2500, sigma=1.6, r_thresh=10.0, extrema_thresh=10.0):
-    return Params(n_octaves, n_scales, max_points, sigma, r_thresh, extrema_thresh)
+def params(n_octaves=4, n_scales=2, max_points=2500, sigma=1.6, r_thresh=10.0, extrema_thresh=10.0,
+           profile=0, upsample=0):
+    return Params(n_octaves, n_scales, max_points, sigma, r_thresh, extrema_thresh, int(profile), int(upsample))
 
 
 def gaussian1d(sigma, n):
@@ -241,6 +250,26 @@ def format_points(pts):
     n = lib().oracle_format_points(pts.ctypes.data, len(pts), buf, cap)
     assert n >= 0
     return buf.raw[:n].decode()
+
+
+def quantize_descriptors(pts):
+    pts = np.ascontiguousarray(pts)
+    out = np.empty((len(pts), 128), np.uint8)
+    lib().oracle_quantize_descriptors(pts.ctypes.data, len(pts), out.ctypes.data)
+    return out
+
+
+def upsample2x(img, w=None):
+    img = np.ascontiguousarray(img, np.float32)
+    h, p = img.shape
+    w = p if w is None else w
+    out = np.empty((2 * h, 2 * w), np.float32)
+    lib().oracle_upsample2x(_fp(img), w, p, h, _fp(out))
+    return out
+
+
+def det_exp2(f):
+    return float(lib().oracle_det_exp2(C.c_double(f)))
 
 
 def sort_points(pts):

@@ -26,6 +26,8 @@ void oracle_default_params(OracleParams *p)
     p->sigma = 1.6f;
     p->r_thresh = 10.0f;
     p->extrema_thresh = 10.0f;
+    p->profile = 0;
+    p->upsample = 0;
 }
 
 int oracle_idivup(int num, int den) { return (num % den != 0) ? (num / den + 1) : (num / den); }
@@ -617,6 +619,147 @@ void oracle_descriptor(const float *grad2, int w, int p, int h, const float *dw,
         out[i] = hist[i] / S2;
 }
 
+/* ---- profile "lowe" ---------------------------------------------------------
+ * Not in the reference.  The pyramid is the reference's (same planes, same
+ * DoG); detection follows D. Lowe's method in the form OpenCV made common:
+ *   start   8 < x < w-8, 8 < y < h-8, |D| > 0.5*T/S, D strictly above or
+ *           strictly below all 26 neighbours in planes c-1, c, c+1
+ *   refine  up to 5 times: gradient g and Hessian H of D by central
+ *           differences, X = -H^-1 g by the adjugate; all |X_k| < 0.5 ends the
+ *           loop; otherwise the sample moves by floor(X_k + 0.5) and the point
+ *           is dropped if it leaves planes 1..S or the border
+ *   reject  |D + 0.5 g.X| * S < T;  det(Hxy) <= 0;  tr^2 * r >= (r+1)^2 * det
+ * T = extrema_thresh, r = r_thresh, S = n_scales.  Single precision, one
+ * operation at a time, in the order written. */
+double oracle_det_exp2(double f)
+{
+    /* exp(f ln 2) by its series in Horner form: |f ln 2| <= 1.39, 22 terms leave < 1e-19 */
+    const double t = f * 0.69314718055994530942;
+    double q = 1.0;
+    for (int k = 22; k >= 1; --k)
+        q = fma(q, t / (double)k, 1.0);
+    return q;
+}
+
+static inline float lowe_dog(const float *blur, long gDim, int p, int s, int x, int y)
+{
+    const float *c = blur + (long)s * gDim + x + (long)p * y;
+    return c[0] - c[gDim]; /* cudaSiftH.cu:190: DoG_s = blur_s - blur_{s+1} */
+}
+
+int oracle_find_extrema_lowe(const OracleParams *pr, const float *blur, int w, int p, int h, int i,
+                             OracleLowePoint *out, int max_out)
+{
+    const int S = pr->n_scales;
+    const long gDim = (long)p * h;
+    const float T = pr->extrema_thresh, r = pr->r_thresh;
+    const float pre = 0.5f * T / (float)S;
+    int n = 0;
+    for (int y0 = 9; y0 < h - 8; ++y0)
+        for (int x0 = 9; x0 < w - 8; ++x0) {
+            int x = x0, y = y0, c = i + 1;
+            float v = lowe_dog(blur, gDim, p, c, x, y);
+            if (!(fabsf(v) > pre))
+                continue;
+            int above = 1, below = 1;
+            for (int s = -1; s < 2; ++s)
+                for (int m = -1; m < 2; ++m)
+                    for (int l = -1; l < 2; ++l) {
+                        if (!s && !m && !l)
+                            continue;
+                        float q = lowe_dog(blur, gDim, p, c + s, x + l, y + m);
+                        above &= v > q;
+                        below &= v < q;
+                    }
+            if (!above && !below)
+                continue;
+            float Xx = 0, Xy = 0, Xs = 0, gx = 0, gy = 0, gs = 0, dxx = 0, dyy = 0, dxy = 0;
+            int ok = 0;
+            for (int it = 0; it < 5; ++it) {
+                float d[3][3][3]; /* [plane][row][column] */
+                for (int s = 0; s < 3; ++s)
+                    for (int m = 0; m < 3; ++m)
+                        for (int l = 0; l < 3; ++l)
+                            d[s][m][l] = lowe_dog(blur, gDim, p, c + s - 1, x + l - 1, y + m - 1);
+                v = d[1][1][1];
+                gx = (d[1][1][2] - d[1][1][0]) * 0.5f;
+                gy = (d[1][2][1] - d[1][0][1]) * 0.5f;
+                gs = (d[2][1][1] - d[0][1][1]) * 0.5f;
+                const float v2 = v * 2.0f;
+                dxx = d[1][1][2] + d[1][1][0] - v2;
+                dyy = d[1][2][1] + d[1][0][1] - v2;
+                const float dss = d[2][1][1] + d[0][1][1] - v2;
+                dxy = (d[1][2][2] - d[1][2][0] - d[1][0][2] + d[1][0][0]) * 0.25f;
+                const float dxs = (d[2][1][2] - d[2][1][0] - d[0][1][2] + d[0][1][0]) * 0.25f;
+                const float dys = (d[2][2][1] - d[2][0][1] - d[0][2][1] + d[0][0][1]) * 0.25f;
+                const float c00 = dyy * dss - dys * dys;
+                const float c01 = dxs * dys - dxy * dss;
+                const float c02 = dxy * dys - dxs * dyy;
+                const float c11 = dxx * dss - dxs * dxs;
+                const float c12 = dxs * dxy - dxx * dys;
+                const float c22 = dxx * dyy - dxy * dxy;
+                const float det = dxx * c00 + dxy * c01 + dxs * c02;
+                if (det == 0.0f)
+                    break;
+                Xx = -(c00 * gx + c01 * gy + c02 * gs) / det;
+                Xy = -(c01 * gx + c11 * gy + c12 * gs) / det;
+                Xs = -(c02 * gx + c12 * gy + c22 * gs) / det;
+                if (fabsf(Xx) < 0.5f && fabsf(Xy) < 0.5f && fabsf(Xs) < 0.5f) {
+                    ok = 1;
+                    break;
+                }
+                if (!(fabsf(Xx) < 1e6f && fabsf(Xy) < 1e6f && fabsf(Xs) < 1e6f))
+                    break; /* also catches NaN */
+                x += (int)floorf(Xx + 0.5f);
+                y += (int)floorf(Xy + 0.5f);
+                c += (int)floorf(Xs + 0.5f);
+                if (c < 1 || c > S || x <= 8 || x >= w - 8 || y <= 8 || y >= h - 8)
+                    break;
+            }
+            if (!ok)
+                continue;
+            const float dhat = v + 0.5f * (gx * Xx + gy * Xy + gs * Xs);
+            if (fabsf(dhat) * (float)S < T)
+                continue;
+            const float tr = dxx + dyy, det2 = dxx * dyy - dxy * dxy;
+            if (det2 <= 0.0f || tr * tr * r >= (r + 1.0f) * (r + 1.0f) * det2)
+                continue;
+            if (n < max_out) {
+                out[n].x = x;
+                out[n].y = y;
+                out[n].c = c;
+                out[n].dx = Xx;
+                out[n].dy = Xy;
+                out[n].ds = Xs;
+            }
+            ++n;
+        }
+    return n;
+}
+
+void oracle_upsample2x(const float *src, int w, int pitch, int h, float *dst)
+{
+    const int W = 2 * w;
+    for (int Y = 0; Y < 2 * h; ++Y)
+        for (int X = 0; X < W; ++X) {
+            const int x0 = X >> 1, y0 = Y >> 1;
+            const int x1 = (X & 1) ? (x0 + 1 < w ? x0 + 1 : x0) : x0;
+            const int y1 = (Y & 1) ? (y0 + 1 < h ? y0 + 1 : y0) : y0;
+            const float a = src[x0 + (long)pitch * y0], b = src[x1 + (long)pitch * y0];
+            const float c = src[x0 + (long)pitch * y1], d = src[x1 + (long)pitch * y1];
+            dst[X + (long)W * Y] = ((a + b) + (c + d)) * 0.25f;
+        }
+}
+
+void oracle_quantize_descriptors(const OracleSiftPoint *pts, int n, unsigned char *out)
+{
+    for (int j = 0; j < n; ++j)
+        for (int k = 0; k < 128; ++k) {
+            float q = floorf(pts[j].data[k] * 512.0f + 0.5f);
+            out[128 * j + k] = (unsigned char)(q > 255.0f ? 255.0f : q);
+        }
+}
+
 /* ---- extractSift cudaSiftH.cu:9-117 --------------------------------------- */
 int oracle_extract(const OracleParams *pr, const float *img, int w, int pitch, int h, int octave0,
                    OracleSiftPoint *pts, unsigned char *meta, int *total_found)
@@ -629,7 +772,24 @@ int oracle_extract(const OracleParams *pr, const float *img, int w, int pitch, i
     float *owned_src = NULL;
     int p = pitch;
     int *xy = (int *)malloc(sizeof(int) * 2 * pr->max_points);
-    for (int o = octave0; o < pr->n_octaves; ++o) {
+    const int lowe = pr->profile == 1;
+    OracleLowePoint *lp = lowe ? (OracleLowePoint *)malloc(sizeof(OracleLowePoint) * pr->max_points) : NULL;
+    int n_oct = pr->n_octaves;
+    double pix = 1.0; /* lowe: input pixels per pixel of the current octave */
+    if (lowe && pr->upsample) { /* one more octave in front, built from the image at twice its size */
+        float *up = (float *)malloc(sizeof(float) * 4L * w * h);
+        oracle_upsample2x(img, w, pitch, h, up);
+        owned_src = up;
+        src = up;
+        w *= 2;
+        h *= 2;
+        p = w;
+        n_oct += 1;
+        pix = 0.5;
+    }
+    for (int k = 0; k < octave0; ++k)
+        pix *= 2.0;
+    for (int o = octave0; o < n_oct; ++o, pix *= 2.0) {
         if (count >= pr->max_points) /* cudaSiftH.cu:12-13 */
             break;
         long gDim = (long)p * h;
@@ -652,7 +812,33 @@ int oracle_extract(const OracleParams *pr, const float *img, int w, int pitch, i
         oracle_dog(pr, blur, dog, w, p, h);
         oracle_hessian(pr, blur, hess, w, p, h);
         oracle_gradient(pr, blur, grad, w, p, h);
-        for (int i = 0; i < S; ++i) { /* computeOctaveSift cudaSiftH.cu:80-116 */
+        for (int i = 0; i < S && lowe; ++i) {
+            if (count >= pr->max_points)
+                break;
+            int room = pr->max_points - count;
+            int n = oracle_find_extrema_lowe(pr, blur, w, p, h, i, lp, room);
+            total += n;
+            if (n > room)
+                n = room;
+            for (int j = 0; j < n; ++j) {
+                OracleSiftPoint *q = &pts[count + j];
+                const int sc = lp[j].c - 1; /* scale index the point ended on */
+                const float *g2 = grad + (long)sc * 2 * gDim;
+                q->xpos = (float)(((double)((float)lp[j].x + lp[j].dx)) * pix);
+                q->ypos = (float)(((double)((float)lp[j].y + lp[j].dy)) * pix);
+                q->scale = (float)((double)pr->sigma * pix *
+                                   oracle_det_exp2((double)((float)sc + lp[j].ds) / (double)S));
+                /* orientation and descriptor at the integer sample, as the reference takes them */
+                q->orientation = oracle_orientation(g2, w, p, h, wnd + sc * 16, lp[j].x, lp[j].y, NULL);
+                oracle_descriptor(g2, w, p, h, dwnd, lp[j].x, lp[j].y, q->orientation, q->data);
+                if (meta) {
+                    meta[2 * (count + j)] = (unsigned char)o;
+                    meta[2 * (count + j) + 1] = (unsigned char)sc;
+                }
+            }
+            count += n;
+        }
+        for (int i = 0; i < S && !lowe; ++i) { /* computeOctaveSift cudaSiftH.cu:80-116 */
             if (count >= pr->max_points)
                 break;
             int room = pr->max_points - count;
@@ -681,7 +867,7 @@ int oracle_extract(const OracleParams *pr, const float *img, int w, int pitch, i
         }
         float *next = NULL;
         int w_ = oracle_idivup(w, 2), h_ = oracle_idivup(h, 2), p_ = oracle_ialignup(w_, 128);
-        if (o + 1 < pr->n_octaves) { /* cudaSiftH.cu:40-55 */
+        if (o + 1 < n_oct) { /* cudaSiftH.cu:40-55 */
             next = (float *)malloc(sizeof(float) * (long)p_ * h_);
             for (long i = 0; i < (long)p_ * h_; ++i)
                 next[i] = NAN;
@@ -701,6 +887,7 @@ int oracle_extract(const OracleParams *pr, const float *img, int w, int pitch, i
     }
     free(owned_src);
     free(xy);
+    free(lp);
     if (total_found)
         *total_found = total;
     return count;

@@ -17,6 +17,14 @@
  * of the input (data races, uninitialised reads, atomic ordering) is replaced
  * by the evident intent with the reference's parameters, and every float sum
  * whose order the reference leaves to atomics is given one fixed order here.
+ *
+ * Semantics profile "lowe" (params.profile = 1) is NOT the reference's
+ * behaviour: it is the feature set the reference lacks -- strict 26-neighbour
+ * extrema on the same pyramid, a 3-D quadratic refinement of position and
+ * scale, contrast and edge rejection on the DoG Hessian with the usual sign,
+ * coordinates in pixels of the input image, optionally an up-sampled first
+ * octave.  Nothing in the reference pins it; it is defined here and by the
+ * comments at oracle_find_extrema_lowe.
  */
 #ifndef SIFT_ORACLE_H
 #define SIFT_ORACLE_H
@@ -42,6 +50,8 @@ typedef struct {
     float sigma;          /* SIGMA 1.6f         utils.h:14 */
     float r_thresh;       /* R_THRESH 10.0f     utils.h:16 */
     float extrema_thresh; /* EXTREMA_THRESH 10.0f utils.h:18 */
+    int profile;          /* 0 = ref, 1 = lowe */
+    int upsample;         /* lowe only: first octave is the image up-sampled by 2 */
 } OracleParams;
 
 #define ORACLE_BLUR_TAPS 19 /* 2*B_KERNEL_RADIUS+1, utils.h:5, cudaSiftD.h:6 */
@@ -100,6 +110,26 @@ float oracle_orientation(const float *grad2, int w, int p, int h, const float *w
 /* DescriptorKernel cudaSiftD.cu:96-214 (intent), one keypoint. */
 void oracle_descriptor(const float *grad2, int w, int p, int h, const float *desc16,
                        int x, int y, float orientation_deg, float *out128);
+
+/* ---- profile "lowe" -------------------------------------------------------
+ * One keypoint of the lowe detector: integer sample it was refined at (octave
+ * grid), DoG plane index c (1..S), and the refined offsets. */
+typedef struct {
+    int x, y, c;
+    float dx, dy, ds; /* each within (-0.5, 0.5) */
+} OracleLowePoint;
+/* 2^f for f in [-1, 2], evaluated in double with a fixed operation sequence */
+double oracle_det_exp2(double f);
+/* Detector of one scale index i (DoG plane i+1 is the starting plane) over the
+ * S+3 blur planes of one octave, raster order of the starting sample.  Returns
+ * the number found (may exceed max_out). */
+int oracle_find_extrema_lowe(const OracleParams *pr, const float *blur, int w, int p, int h, int i,
+                             OracleLowePoint *out, int max_out);
+/* dst (2w x 2h, pitch 2w): dst[2y][2x] = src[y][x], odd samples are the mean of
+ * their two (or four) even neighbours, the last odd row/column repeats the edge */
+void oracle_upsample2x(const float *src, int w, int pitch, int h, float *dst);
+/* 8-bit descriptors: min(255, round-half-up(512 * v)) */
+void oracle_quantize_descriptors(const OracleSiftPoint *pts, int n, unsigned char *out);
 
 /* extractSift cudaSiftH.cu:9-60 for octaves octave0..n_octaves-1.
  * pts: capacity max_points.  meta (optional, 2 bytes per point): octave, scale

@@ -38,7 +38,12 @@ class Params(C.Structure):
         ("sigma", C.c_float),
         ("r_thresh", C.c_float),
         ("extrema_thresh", C.c_float),
+        ("profile", C.c_int),
+        ("upsample", C.c_int),
     ]
+
+
+PROFILE_REF, PROFILE_LOWE = 0, 1
 
 
 # every symbol include/sift_amd.h declares: (restype, argtypes)
@@ -62,6 +67,7 @@ SYMBOLS = {
     "sift_shutdown": (None, []),
     "sift_extract_batch": (C.c_int, [_vp, _vp, _ip, _vp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "sift_extract_batch_u8": (C.c_int, [_vp, _vp, _ip, _vp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "sift_quantize_descriptors": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "sift_set_batch_chunk": (None, [C.c_int]),
     "sift_set_batch_lanes": (None, [C.c_int]),
     "sift_set_queue_cap": (None, [C.c_int]),
@@ -137,8 +143,9 @@ def default_params():
     return p
 
 
-def set_params(n_octaves=4, n_scales=2, max_points=2500, sigma=1.6, r_thresh=10.0, extrema_thresh=10.0):
-    p = Params(n_octaves, n_scales, max_points, sigma, r_thresh, extrema_thresh)
+def set_params(n_octaves=4, n_scales=2, max_points=2500, sigma=1.6, r_thresh=10.0, extrema_thresh=10.0,
+               profile=PROFILE_REF, upsample=0):
+    p = Params(n_octaves, n_scales, max_points, sigma, r_thresh, extrema_thresh, int(profile), int(upsample))
     _ok(lib().sift_set_params(C.byref(p)))
     return p
 
@@ -291,6 +298,15 @@ def extract_batch(d_imgs, width, want_meta=False, stream=None, d_pts=None):
                _stream_ptr(stream))
     _ok(rc)
     return (d_pts, counts, meta) if want_meta else (d_pts, counts)
+
+
+def quantize_descriptors(d_pts, n, stream=None):
+    """8-bit descriptors of the first n points of a device point tensor: (n, 128) uint8 tensor."""
+    import torch
+
+    out = torch.empty((max(n, 0), 128), dtype=torch.uint8, device=d_pts.device)
+    _ok(lib().sift_quantize_descriptors(_dev_f32(d_pts), n, C.c_void_p(out.data_ptr()), _stream_ptr(stream)))
+    return out
 
 
 def timing_enable(on=True):

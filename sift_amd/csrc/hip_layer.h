@@ -37,6 +37,11 @@ typedef struct {
     int n_scales, n_oct, cap;
     float edge_limit;   /* (r_thresh^2)/r_thresh, cudaSiftD.cu:292 */
     float contrast;     /* EXTREMA_THRESH, cudaSiftD.cu:293 */
+    /* profile "lowe" only */
+    float pre_thresh;   /* 0.5 * contrast / n_scales: the test a sample must pass to be examined */
+    float r_thresh;     /* edge ratio r */
+    float sigma;        /* base sigma */
+    float pix[HL_MAX_OCT]; /* input pixels per pixel of each octave (a power of two) */
     hl_octave oct[HL_MAX_OCT];
     int band0[HL_MAX_OCT + 1];  /* first 32-row band of each octave (alias pre-filter units) */
     int dense0[HL_MAX_OCT + 1]; /* first 256x32-pixel block of each octave (dense detector units) */
@@ -102,12 +107,14 @@ int hl_col_blur_dog(const float *tmp, long tmp_stride, float *blur, long blur_st
  * queue != NULL: pixels passing the detector's contrast and border tests (rows
  * with y mod 32 >= 30 excepted) are queued per scale: entry (x | y<<16) at
  * queue[i*qcap + k], count in qcount[group0 + i]; a count above qcap means the
- * queue is incomplete and the dense detector must redo that scale. */
+ * queue is incomplete and the dense detector must redo that scale.
+ * plain != 0: every sample inside the border qualifies (profile "lowe"); 0: the
+ * reference's tile rules apply (rows with y mod 32 >= 30 and middle tiles excepted). */
 int hl_pyramid(const void *src, int src_w, int src_h, int src_pitch, long src_stride, int src_mode,
                float *blur, long blur_stride, int w, int p, int h,
                int n_scales, int nimg, const hl_taps *taps, float contrast, unsigned *queue,
                long queue_stride, unsigned *qcount, long qcount_stride, int qcap, int group0,
-               void *stream);
+               int plain, void *stream);
 /* The three detection launches cover every octave of the launch set.
  * hl_alias_prefilter: queues the pixels whose centre value the reference reads
  *   through an aliased shared-memory cell (y mod 32 in {30,31}).
@@ -127,9 +134,27 @@ int hl_detect(const float *arena, long arena_stride, unsigned *cand, long cand_s
 /* orientation + descriptor for every candidate; writes SiftPoint records
  * behind base_count[z] and meta (may be NULL) */
 int hl_keypoints(void *pts, long pts_stride_points, unsigned char *meta, const float *arena,
-                 long arena_stride, const unsigned *cand, long cand_stride,
+                 long arena_stride, const unsigned *cand, const void *sub, long cand_stride,
                  const unsigned *counts, long counts_stride, const unsigned *base_count,
                  const hl_keypoint_args *args, int nimg, void *stream);
+/* Profile "lowe" (not in the reference).  sub: one 16-byte record per candidate
+ * slot beside cand (x, y in input pixels, scale, DoG plane index); NULL in
+ * hl_keypoints means profile "ref".
+ * hl_verify_lowe: strict extremum + refinement + rejection over the queues.
+ * hl_detect_lowe: the same over every pixel of the groups whose queue overflowed
+ *   (gate = the queue counters) or of all groups (gate NULL).
+ * hl_upsample2x: float or 8-bit image -> float image of twice the size. */
+int hl_verify_lowe(const float *arena, long arena_stride, const unsigned *queue, long queue_stride,
+                   const unsigned *qcount, long qcount_stride, unsigned *cand, void *sub,
+                   long cand_stride, unsigned *counts, long counts_stride, const hl_detect_args *a,
+                   int nimg, void *stream);
+int hl_detect_lowe(const float *arena, long arena_stride, unsigned *cand, void *sub, long cand_stride,
+                   unsigned *counts, long counts_stride, const unsigned *gate, long gate_stride,
+                   const hl_detect_args *a, int nimg, void *stream);
+int hl_upsample2x(const void *src, int src_u8, int src_pitch, long src_stride, float *dst, int dst_pitch,
+                  long dst_stride, int w, int h, int nimg, void *stream);
+/* out[128*j + k] = min(255, round(512 * pts[j].data[k])) */
+int hl_quantize(const void *pts, int n, unsigned char *out, void *stream);
 /* base_count[z] = min(base_count[z] + sum(min(counts, cap)), cap) */
 int hl_finalize_counts(unsigned *base_count, const unsigned *counts, long counts_stride,
                        int n_groups, int cap, int nimg, void *stream);

@@ -28,7 +28,10 @@
 typedef struct {
     int valid;
     /* signature the arena was planned for */
-    int w, h, S, O, oct0, cap, nimg, queue_cap;
+    int w, h, S, O, oct0, cap, nimg, queue_cap, profile, upsample;
+    int n_oct;         /* octaves processed: O - oct0, plus one in front when up-sampling */
+    long up_off;       /* the up-sampled image (2w x 2h, pitch 2w), profile "lowe" with upsample */
+    void *sub;         /* profile "lowe": nimg * groups * cap 16-byte records beside cand */
     float *arena;
     long arena_stride; /* floats per image */
     int ow[SIFT_MAX_OCTAVES], oh[SIFT_MAX_OCTAVES], op[SIFT_MAX_OCTAVES];
@@ -44,7 +47,7 @@ typedef struct {
 } slot_ctx;
 
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
-static sift_params g_params = {4, 2, 2500, 1.6f, 10.0f, 10.0f};
+static sift_params g_params = {4, 2, 2500, 1.6f, 10.0f, 10.0f, 0, 0};
 static int g_tables_ready = 0;
 static float g_blur[HL_MAX_PLANES * HL_TAPS];
 static float g_wnd[4 * 16];
@@ -151,10 +154,20 @@ void sift_default_params(sift_params *p)
     p->sigma = 1.6f;
     p->r_thresh = 10.0f;
     p->extrema_thresh = 10.0f;
+    p->profile = SIFT_PROFILE_REF;
+    p->upsample = 0;
 }
 
 int sift_set_params(const sift_params *p)
 {
+    if (p->profile != SIFT_PROFILE_REF && p->profile != SIFT_PROFILE_LOWE) {
+        set_err("profile %d: 0 (ref) or 1 (lowe)", p->profile);
+        return -1;
+    }
+    if (p->upsample && (p->profile != SIFT_PROFILE_LOWE || p->n_octaves + 1 > SIFT_MAX_OCTAVES)) {
+        set_err("upsample needs profile lowe and n_octaves < %d", SIFT_MAX_OCTAVES);
+        return -1;
+    }
     if (p->n_octaves < 1 || p->n_octaves > SIFT_MAX_OCTAVES) {
         set_err("n_octaves %d outside 1..%d", p->n_octaves, SIFT_MAX_OCTAVES);
         return -1;
@@ -208,6 +221,7 @@ static void free_slot(slot_ctx *c)
     if (c->counts) hl_free(c->counts);
     if (c->cand) hl_free(c->cand);
     if (c->queue) hl_free(c->queue);
+    if (c->sub) hl_free(c->sub);
     memset(c, 0, sizeof *c);
 }
 
@@ -264,8 +278,10 @@ static int ensure_slot_counter(int dev)
 static int ensure_arena(slot_ctx *c, int w, int h, int oct0, int nimg)
 {
     const int S = g_params.n_scales, O = g_params.n_octaves, cap = g_params.max_points;
+    const int lowe = g_params.profile == SIFT_PROFILE_LOWE, up = lowe && g_params.upsample;
     if (c->valid && c->w == w && c->h == h && c->S == S && c->O == O && c->oct0 == oct0 &&
-        c->cap == cap && c->nimg >= nimg && c->queue_cap == g_queue_cap)
+        c->cap == cap && c->nimg >= nimg && c->queue_cap == g_queue_cap &&
+        c->profile == g_params.profile && c->upsample == up)
         return 0;
     if (c->valid) { /* geometry changed: drain the slot before its memory goes away */
         int r = hl_stream_sync(c->last_stream);
@@ -274,12 +290,16 @@ static int ensure_arena(slot_ctx *c, int w, int h, int oct0, int nimg)
     free_slot(c);
 
     long off = 0, qoff = 0;
-    int ww = w, hh = h, qc = g_queue_cap > 0 ? g_queue_cap : 1;
-    for (int o = oct0; o < O; ++o) {
-        const int oi = o - oct0;
+    int ww = up ? 2 * w : w, hh = up ? 2 * h : h, qc = g_queue_cap > 0 ? g_queue_cap : 1;
+    const int n_oct = O - oct0 + (up ? 1 : 0);
+    if (up) {
+        c->up_off = 0;
+        off = lalign(4L * w * h, 64);
+    }
+    for (int oi = 0; oi < n_oct; ++oi) {
         c->ow[oi] = ww;
         c->oh[oi] = hh;
-        c->op[oi] = (o == oct0) ? ialignup(ww, 64) : ialignup(ww, 128); /* cudaSiftH.cu:46 */
+        c->op[oi] = (oi == 0) ? ialignup(ww, 64) : ialignup(ww, 128); /* cudaSiftH.cu:46 */
         c->blur_off[oi] = off;
         off += lalign((long)c->op[oi] * hh * (S + 3), 64);
         c->qcap[oi] = qc;
@@ -291,7 +311,7 @@ static int ensure_arena(slot_ctx *c, int w, int h, int oct0, int nimg)
     }
     c->queue_stride = qoff;
     c->arena_stride = off;
-    const int groups = (O - oct0) * S;
+    const int groups = n_oct * S;
     void *p = NULL;
     int r = hl_malloc(&p, sizeof(float) * (size_t)off * nimg);
     if (r) return fail_hl(r, "allocating arena");
@@ -306,6 +326,14 @@ static int ensure_arena(slot_ctx *c, int w, int h, int oct0, int nimg)
     r = hl_malloc(&p, sizeof(unsigned) * (size_t)c->cand_stride * nimg);
     if (r) return fail_hl(r, "allocating candidate lists");
     c->cand = (unsigned *)p;
+    if (lowe) {
+        r = hl_malloc(&p, 16 * (size_t)c->cand_stride * nimg);
+        if (r) return fail_hl(r, "allocating refined-point records");
+        c->sub = p;
+    }
+    c->n_oct = n_oct;
+    c->profile = g_params.profile;
+    c->upsample = up;
     c->w = w;
     c->h = h;
     c->S = S;
@@ -326,7 +354,8 @@ static int enqueue_extract(slot_ctx *c, SiftPoint *pts, unsigned char *meta, con
                            int imgs_u8, long img_stride, int nimg, int pitch, int oct0,
                            unsigned *base_count, void *stream)
 {
-    const int S = g_params.n_scales, O = g_params.n_octaves, cap = g_params.max_points;
+    const int S = g_params.n_scales, cap = g_params.max_points;
+    const int lowe = c->profile == SIFT_PROFILE_LOWE, up = c->upsample, n_oct = c->n_oct;
     int r = hl_memset_async(c->counts, 0, sizeof(unsigned) * COUNT_WORDS * nimg, stream);
     if (r) return fail_hl(r, "resetting group counters");
     float *A = c->arena;
@@ -336,12 +365,24 @@ static int enqueue_extract(slot_ctx *c, SiftPoint *pts, unsigned char *meta, con
     hl_detect_args da;
     memset(&da, 0, sizeof da);
     da.n_scales = S;
-    da.n_oct = O - oct0;
+    da.n_oct = n_oct;
     da.cap = cap;
     da.edge_limit = (g_params.r_thresh * g_params.r_thresh) / g_params.r_thresh; /* cudaSiftD.cu:292 */
     da.contrast = g_params.extrema_thresh;
-    for (int o = oct0; o < O; ++o) {
-        const int oi = o - oct0;
+    da.pre_thresh = 0.5f * g_params.extrema_thresh / (float)S;
+    da.r_thresh = g_params.r_thresh;
+    da.sigma = g_params.sigma;
+    /* the test the pyramid pass applies before it queues a sample */
+    const float queue_thresh = lowe ? da.pre_thresh : da.contrast;
+    float pix = up ? 0.5f : 1.0f;
+    for (int k = 0; k < oct0; ++k)
+        pix *= 2.0f;
+    if (up) {
+        r = hl_upsample2x(imgs, imgs_u8, pitch, img_stride, A + c->up_off, 2 * c->w, AS, c->w, c->h, nimg,
+                          stream);
+        if (r) return fail_hl(r, "up-sampling");
+    }
+    for (int oi = 0; oi < n_oct; ++oi, pix *= 2.0f) {
         const int ww = c->ow[oi], hh = c->oh[oi], pp = c->op[oi];
         da.oct[oi].w = ww;
         da.oct[oi].h = hh;
@@ -349,55 +390,71 @@ static int enqueue_extract(slot_ctx *c, SiftPoint *pts, unsigned char *meta, con
         da.oct[oi].qcap = c->qcap[oi];
         da.oct[oi].blur_off = c->blur_off[oi];
         da.oct[oi].queue_off = c->queue_off[oi];
+        da.pix[oi] = pix;
         da.band0[oi + 1] = da.band0[oi] + idivup(hh, 32);
         da.dense0[oi + 1] = da.dense0[oi] + idivup(ww, 256) * idivup(hh, 32);
-        if (o == oct0)
-            r = hl_pyramid(imgs, ww, hh, pitch, img_stride, imgs_u8 ? 1 : 0, A + c->blur_off[oi], AS,
-                           ww, pp, hh, S, nimg, &g_taps, da.contrast,
-                           prefilter ? c->queue + c->queue_off[oi] : NULL, c->queue_stride, queued,
-                           COUNT_WORDS, c->qcap[oi], oi * S, stream);
+        unsigned *q = prefilter ? c->queue + c->queue_off[oi] : NULL;
+        if (oi == 0 && up)
+            r = hl_pyramid(A + c->up_off, ww, hh, ww, AS, 0, A + c->blur_off[oi], AS, ww, pp, hh, S, nimg,
+                           &g_taps, queue_thresh, q, c->queue_stride, queued, COUNT_WORDS, c->qcap[oi],
+                           oi * S, lowe, stream);
+        else if (oi == 0)
+            r = hl_pyramid(imgs, ww, hh, pitch, img_stride, imgs_u8 ? 1 : 0, A + c->blur_off[oi], AS, ww,
+                           pp, hh, S, nimg, &g_taps, queue_thresh, q, c->queue_stride, queued,
+                           COUNT_WORDS, c->qcap[oi], oi * S, lowe, stream);
         else /* cudaSiftH.cu:50-52: the next octave is the even pixels of blur plane S */
             r = hl_pyramid(A + c->blur_off[oi - 1] + (long)S * c->op[oi - 1] * c->oh[oi - 1],
                            c->ow[oi - 1], c->oh[oi - 1], c->op[oi - 1], AS, 2, A + c->blur_off[oi],
-                           AS, ww, pp, hh, S, nimg, &g_taps, da.contrast,
-                           prefilter ? c->queue + c->queue_off[oi] : NULL, c->queue_stride, queued,
-                           COUNT_WORDS, c->qcap[oi], oi * S, stream);
+                           AS, ww, pp, hh, S, nimg, &g_taps, queue_thresh, q, c->queue_stride, queued,
+                           COUNT_WORDS, c->qcap[oi], oi * S, lowe, stream);
         if (r) return fail_hl(r, "pyramid pass");
     }
-    /* detection, once for all octaves: the pixels whose centre value the reference
-     * reads through an aliased cell join the queues, the queues are verified, and
-     * (only where a queue overflowed) a dense pass redoes the group */
-    if (prefilter) {
-        r = hl_alias_prefilter(A, AS, c->queue, c->queue_stride, queued, COUNT_WORDS, &da, nimg, stream);
-        if (r) return fail_hl(r, "aliased-row pre-filter");
-        r = hl_verify(A, AS, c->queue, c->queue_stride, queued, COUNT_WORDS, c->cand, c->cand_stride,
-                      c->counts, COUNT_WORDS, &da, nimg, stream);
-        if (r) return fail_hl(r, "candidate verification");
+    if (lowe) {
+        /* strict extrema, refinement and rejection over the queues; a dense pass
+         * redoes the groups whose queue overflowed */
+        if (prefilter) {
+            r = hl_verify_lowe(A, AS, c->queue, c->queue_stride, queued, COUNT_WORDS, c->cand, c->sub,
+                               c->cand_stride, c->counts, COUNT_WORDS, &da, nimg, stream);
+            if (r) return fail_hl(r, "candidate refinement");
+        }
+        r = hl_detect_lowe(A, AS, c->cand, c->sub, c->cand_stride, c->counts, COUNT_WORDS,
+                           prefilter ? queued : NULL, COUNT_WORDS, &da, nimg, stream);
+        if (r) return fail_hl(r, "dense detection");
+    } else {
+        /* detection, once for all octaves: the pixels whose centre value the reference
+         * reads through an aliased cell join the queues, the queues are verified, and
+         * (only where a queue overflowed) a dense pass redoes the group */
+        if (prefilter) {
+            r = hl_alias_prefilter(A, AS, c->queue, c->queue_stride, queued, COUNT_WORDS, &da, nimg, stream);
+            if (r) return fail_hl(r, "aliased-row pre-filter");
+            r = hl_verify(A, AS, c->queue, c->queue_stride, queued, COUNT_WORDS, c->cand, c->cand_stride,
+                          c->counts, COUNT_WORDS, &da, nimg, stream);
+            if (r) return fail_hl(r, "candidate verification");
+        }
+        r = hl_detect(A, AS, c->cand, c->cand_stride, c->counts, COUNT_WORDS, prefilter ? queued : NULL,
+                      COUNT_WORDS, &da, nimg, stream);
+        if (r) return fail_hl(r, "dense detection");
     }
-    r = hl_detect(A, AS, c->cand, c->cand_stride, c->counts, COUNT_WORDS, prefilter ? queued : NULL,
-                  COUNT_WORDS, &da, nimg, stream);
-    if (r) return fail_hl(r, "dense detection");
     hl_keypoint_args ka;
     memset(&ka, 0, sizeof ka);
     ka.n_scales = S;
-    ka.n_groups = (O - oct0) * S;
+    ka.n_groups = n_oct * S;
     ka.first_octave = oct0;
     ka.cap = cap;
-    for (int o = oct0; o < O; ++o) {
-        const int oi = o - oct0;
+    for (int oi = 0; oi < n_oct; ++oi) {
         ka.oct[oi].w = c->ow[oi];
         ka.oct[oi].h = c->oh[oi];
         ka.oct[oi].p = c->op[oi];
         ka.oct[oi].blur_off = c->blur_off[oi];
         for (int i = 0; i < S; ++i)
-            ka.scale_value[oi * S + i] = scale_value(i, o);
+            ka.scale_value[oi * S + i] = scale_value(i, oct0 + oi);
     }
     memcpy(ka.wnd, g_wnd, sizeof(float) * S * 16);
     memcpy(ka.desc_wnd, g_desc, sizeof g_desc);
     memcpy(ka.cos32, g_cos32, sizeof g_cos32);
     memcpy(ka.sin32, g_sin32, sizeof g_sin32);
-    r = hl_keypoints(pts, cap, meta, A, AS, c->cand, c->cand_stride, c->counts, COUNT_WORDS,
-                     base_count, &ka, nimg, stream);
+    r = hl_keypoints(pts, cap, meta, A, AS, c->cand, lowe ? c->sub : NULL, c->cand_stride, c->counts,
+                     COUNT_WORDS, base_count, &ka, nimg, stream);
     if (r) return fail_hl(r, "keypoint kernel");
     r = hl_finalize_counts(base_count, c->counts, COUNT_WORDS, ka.n_groups, cap, nimg, stream);
     if (r) return fail_hl(r, "count update");
@@ -450,6 +507,10 @@ void extractSift(SiftPoint *siftPt, float *d_src, int width, int pitch, int heig
         }
         if (octaveIdx < 0 || octaveIdx >= g_params.n_octaves) /* cudaSiftH.cu:41: nothing to do */
             break;
+        if (octaveIdx > 0 && g_params.upsample) {
+            set_err("extractSift: octaveIdx must be 0 when the first octave is up-sampled");
+            break;
+        }
         int dev = hl_get_device();
         if (dev < 0 || dev >= MAX_DEV) {
             set_err("extractSift: no usable HIP device");
@@ -608,6 +669,12 @@ static int extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
     } while (0);
     pthread_mutex_unlock(&g_mu);
     return rc;
+}
+
+int sift_quantize_descriptors(const SiftPoint *d_pts, int n, unsigned char *d_out, void *stream)
+{
+    int r = hl_quantize(d_pts, n, d_out, stream);
+    return r ? fail_hl(r, "sift_quantize_descriptors") : 0;
 }
 
 int sift_extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts, const float *d_imgs,

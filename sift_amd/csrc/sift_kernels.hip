@@ -277,7 +277,8 @@ template <int S, int SRC_MODE>
 __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     const float *__restrict__ src, int src_w, int src_h, int src_pitch, long src_stride,
     float *__restrict__ blur, long blur_stride, int w, int p, int h, int rows, hl_taps taps, float contrast, unsigned *__restrict__ queue,
-    long queue_stride, unsigned *__restrict__ qcount, long qcount_stride, int qcap, int group0)
+    long queue_stride, unsigned *__restrict__ qcount, long qcount_stride, int qcap, int group0,
+    int plain)
 {
     constexpr int NP = S + 3;
     __shared__ float lds[2][128];
@@ -329,7 +330,9 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     const bool pre = queue != nullptr;
     const int xq = x0 + lane;
     const int xq_tile = (xq % XT_DATAX) / XT_BDIM;
-    const bool pre_lane = xq > 8 && xq < w - 8 && xq_tile != 1;
+    // plain: every column and row inside the border qualifies (the detector of the
+    // "lowe" profile has no tiles)
+    const bool pre_lane = xq > 8 && xq < w - 8 && (plain || xq_tile != 1);
     const bool pre_lane0 = pre_lane && xq_tile == 0; // rows with y mod 32 = 30: see alias_prefilter_kernel
     if (lane < S) lq_n[lane] = 0;
 
@@ -458,8 +461,8 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
             // y mod 32 = 30) are left to alias_prefilter_kernel.  No global memory
             // is touched here, so the counted waits of the row loop stay exact.
             const int yo = y0 + r - 2 * RADIUS;
-            if (pre && valid && yo > 8 && yo < h - 8 && (yo & 31) < 31) { // wave-uniform
-                const unsigned long long lanes = (yo & 31) == 30 ? pre_mask0 : pre_mask;
+            if (pre && valid && yo > 8 && yo < h - 8 && (plain || (yo & 31) < 31)) { // wave-uniform
+                const unsigned long long lanes = (!plain && (yo & 31) == 30) ? pre_mask0 : pre_mask;
 #pragma unroll
                 for (int i = 0; i < S; ++i) {
                     const unsigned long long hits = __ballot(fabsf(__fsub_rn(b[i + 1], b[i + 2])) > contrast) & lanes;
@@ -918,6 +921,246 @@ __global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ a
 }
 
 // ---------------------------------------------------------------------------
+// Detector of the "lowe" profile (not in the reference): strict 26-neighbour
+// extremum of the DoG, 3-D quadratic refinement, contrast and edge rejection on
+// the DoG Hessian.  Single precision, one operation at a time in the order
+// written (the build has contraction off), so the host restatement gives the
+// same bits.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double det_exp2(double f)
+{
+    // exp(f ln 2) by its series in Horner form: |f ln 2| <= 1.39, 22 terms leave < 1e-19
+    const double t = f * 0.69314718055994530942;
+    double q = 1.0;
+#pragma unroll
+    for (int k = 22; k >= 1; --k) q = fma(q, t / (double)k, 1.0);
+    return q;
+}
+
+// DoG planes c-1, c, c+1 at the 3x3 neighbourhood of (x, y): blur planes c-1..c+2,
+// twelve 12-byte loads
+__device__ __forceinline__ void lowe_cube(const float *__restrict__ blur0, long plane, int p, int c,
+                                          int x, int y, float (&d)[3][3][3])
+{
+    const float *q = blur0 + (c - 1) * plane + x + (long)p * y;
+    float v[4][3][3];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int m = -1; m < 2; ++m) {
+            const float3u t = *reinterpret_cast<const float3u *>(q + s * plane + m * p - 1);
+            v[s][m + 1][0] = t.a, v[s][m + 1][1] = t.b, v[s][m + 1][2] = t.c;
+        }
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) d[s][m][l] = __fsub_rn(v[s][m][l], v[s + 1][m][l]);
+}
+
+struct LoweHit {
+    unsigned xy; // sample the point was refined at
+    float4 sub;  // x, y in input pixels, scale, DoG plane index (as an integer's bits)
+};
+
+// blur0: blur plane 0 of the octave.  (x, y): starting sample, i: scale index.
+__device__ __forceinline__ bool lowe_candidate(const float *__restrict__ blur0, long plane, int w,
+                                               int p, int h, int S, float T, float r, float pre,
+                                               float sigma, float pix, int x, int y, int i,
+                                               LoweHit &out)
+{
+    int c = i + 1;
+    float d[3][3][3];
+    lowe_cube(blur0, plane, p, c, x, y, d);
+    float v = d[1][1][1];
+    if (!(fabsf(v) > pre)) return false;
+    bool above = true, below = true;
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+                if (s != 1 || m != 1 || l != 1) {
+                    above = above && v > d[s][m][l];
+                    below = below && v < d[s][m][l];
+                }
+    if (!above && !below) return false;
+    float Xx = 0.f, Xy = 0.f, Xs = 0.f, gx = 0.f, gy = 0.f, gs = 0.f, dxx = 0.f, dyy = 0.f, dxy = 0.f;
+    bool ok = false;
+    for (int it = 0; it < 5; ++it) {
+        if (it) lowe_cube(blur0, plane, p, c, x, y, d);
+        v = d[1][1][1];
+        gx = (d[1][1][2] - d[1][1][0]) * 0.5f;
+        gy = (d[1][2][1] - d[1][0][1]) * 0.5f;
+        gs = (d[2][1][1] - d[0][1][1]) * 0.5f;
+        const float v2 = v * 2.0f;
+        dxx = d[1][1][2] + d[1][1][0] - v2;
+        dyy = d[1][2][1] + d[1][0][1] - v2;
+        const float dss = d[2][1][1] + d[0][1][1] - v2;
+        dxy = (d[1][2][2] - d[1][2][0] - d[1][0][2] + d[1][0][0]) * 0.25f;
+        const float dxs = (d[2][1][2] - d[2][1][0] - d[0][1][2] + d[0][1][0]) * 0.25f;
+        const float dys = (d[2][2][1] - d[2][0][1] - d[0][2][1] + d[0][0][1]) * 0.25f;
+        const float c00 = dyy * dss - dys * dys;
+        const float c01 = dxs * dys - dxy * dss;
+        const float c02 = dxy * dys - dxs * dyy;
+        const float c11 = dxx * dss - dxs * dxs;
+        const float c12 = dxs * dxy - dxx * dys;
+        const float c22 = dxx * dyy - dxy * dxy;
+        const float det = dxx * c00 + dxy * c01 + dxs * c02;
+        if (det == 0.0f) break;
+        Xx = -(c00 * gx + c01 * gy + c02 * gs) / det;
+        Xy = -(c01 * gx + c11 * gy + c12 * gs) / det;
+        Xs = -(c02 * gx + c12 * gy + c22 * gs) / det;
+        if (fabsf(Xx) < 0.5f && fabsf(Xy) < 0.5f && fabsf(Xs) < 0.5f) {
+            ok = true;
+            break;
+        }
+        if (!(fabsf(Xx) < 1e6f && fabsf(Xy) < 1e6f && fabsf(Xs) < 1e6f)) break; // also catches NaN
+        x += (int)floorf(Xx + 0.5f);
+        y += (int)floorf(Xy + 0.5f);
+        c += (int)floorf(Xs + 0.5f);
+        if (c < 1 || c > S || x <= 8 || x >= w - 8 || y <= 8 || y >= h - 8) break;
+    }
+    if (!ok) return false;
+    const float dhat = v + 0.5f * (gx * Xx + gy * Xy + gs * Xs);
+    if (fabsf(dhat) * (float)S < T) return false;
+    const float tr = dxx + dyy, det2 = dxx * dyy - dxy * dxy;
+    if (det2 <= 0.0f || tr * tr * r >= (r + 1.0f) * (r + 1.0f) * det2) return false;
+    out.xy = (unsigned)x | ((unsigned)y << 16);
+    out.sub.x = (float)((double)((float)x + Xx) * (double)pix);
+    out.sub.y = (float)((double)((float)y + Xy) * (double)pix);
+    out.sub.z = (float)((double)sigma * (double)pix * det_exp2((double)((float)(c - 1) + Xs) / (double)S));
+    out.sub.w = __int_as_float(c);
+    return true;
+}
+
+// wave-aggregated append of a point and its refined values
+__device__ __forceinline__ void append_lowe(bool hit, const LoweHit &hv, int lane, unsigned *count,
+                                            unsigned *list, float4 *sub, int cap)
+{
+    const unsigned long long m = __ballot(hit);
+    if (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(count, (unsigned)__popcll(m));
+        base = __shfl(base, leader);
+        const unsigned idx = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (hit && idx < (unsigned)cap) {
+            list[idx] = hv.xy;
+            sub[idx] = hv.sub;
+        }
+    }
+}
+
+// Queue-driven: one thread per contrast candidate queued by pyramid_kernel.
+// blockIdx.y = (octave, scale) group.
+template <int S>
+__global__ __launch_bounds__(256) void verify_lowe_kernel(
+    const float *__restrict__ arena, long arena_stride, const unsigned *queue, long queue_stride,
+    const unsigned *qcount, long qcount_stride, unsigned *cand, float4 *sub, long cand_stride,
+    unsigned *counts, long counts_stride, hl_detect_args a)
+{
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.y, z = blockIdx.z;
+    const int oi = g / S, i = g - oi * S;
+    const hl_octave oc = a.oct[oi];
+    const unsigned n = qcount[z * qcount_stride + g];
+    if (n == 0 || n > (unsigned)oc.qcap) return; // overflow: the dense kernel takes this group
+    const long plane = (long)oc.p * oc.h;
+    const float *blur0 = arena + z * arena_stride + oc.blur_off;
+    queue += z * queue_stride + oc.queue_off + (long)i * oc.qcap;
+    cand += z * cand_stride + (long)g * a.cap;
+    sub += z * cand_stride + (long)g * a.cap;
+    counts += z * counts_stride + g;
+    const unsigned step = gridDim.x * 256;
+    for (unsigned e0 = blockIdx.x * 256; e0 < n; e0 += step) { // block-uniform trip count
+        const unsigned e = e0 + threadIdx.x;
+        bool hit = false;
+        LoweHit hv;
+        hv.xy = 0;
+        hv.sub = float4{0.f, 0.f, 0.f, 0.f};
+        if (e < n) {
+            const unsigned xy = queue[e];
+            hit = lowe_candidate(blur0, plane, oc.w, oc.p, oc.h, S, a.contrast, a.r_thresh, a.pre_thresh,
+                                 a.sigma, a.pix[oi], (int)(xy & 0xffffu), (int)(xy >> 16), i, hv);
+        }
+        append_lowe(hit, hv, lane, counts, cand, sub, a.cap);
+    }
+}
+
+// Dense form of the same detector, for the groups whose queue overflowed (gate)
+// or for everything (gate NULL).  A block walks over 256 x 32 pixel units.
+template <int S>
+__global__ __launch_bounds__(256) void detect_lowe_kernel(
+    const float *__restrict__ arena, long arena_stride, unsigned *cand, float4 *sub, long cand_stride,
+    unsigned *counts, long counts_stride, const unsigned *gate, long gate_stride, hl_detect_args a)
+{
+    const int lane = threadIdx.x & 63;
+    const int z = blockIdx.z;
+    cand += z * cand_stride;
+    sub += z * cand_stride;
+    counts += z * counts_stride;
+    if (gate) {
+        gate += z * gate_stride;
+        bool any = false;
+        for (int g = 0; g < a.n_oct * S; ++g) any = any || gate[g] > (unsigned)a.oct[g / S].qcap;
+        if (!any) return; // block-uniform
+    }
+    for (int unit = blockIdx.x; unit < a.dense0[a.n_oct]; unit += gridDim.x) {
+        const int oi = find_octave(a.dense0, a.n_oct, unit);
+        const hl_octave oc = a.oct[oi];
+        const int w = oc.w, h = oc.h, p = oc.p;
+        const int xblocks = (w + 255) / 256;
+        const int u = unit - a.dense0[oi];
+        const int x = (u % xblocks) * 256 + threadIdx.x;
+        const int yb = (u / xblocks) * 32;
+        const long plane = (long)p * h;
+        const float *blur0 = arena + z * arena_stride + oc.blur_off;
+        for (int i = 0; i < S; ++i) {
+            const int g = oi * S + i;
+            if (gate && gate[g] <= (unsigned)oc.qcap) continue; // block-uniform
+            for (int ry = 0; ry < 32; ++ry) { // wave-uniform trip count
+                const int y = yb + ry;
+                bool hit = false;
+                LoweHit hv;
+                hv.xy = 0;
+                hv.sub = float4{0.f, 0.f, 0.f, 0.f};
+                if (x > 8 && x < w - 8 && y > 8 && y < h - 8) {
+                    const float *c = blur0 + (i + 1) * plane + x + (long)p * y;
+                    if (fabsf(__fsub_rn(c[0], c[plane])) > a.pre_thresh)
+                        hit = lowe_candidate(blur0, plane, w, p, h, S, a.contrast, a.r_thresh, a.pre_thresh,
+                                             a.sigma, a.pix[oi], x, y, i, hv);
+                }
+                append_lowe(hit, hv, lane, &counts[g], cand + (long)g * a.cap, sub + (long)g * a.cap, a.cap);
+            }
+        }
+    }
+}
+
+// First octave of the "lowe" profile with up-sampling: dst (2w x 2h) holds src
+// at its even samples and the mean of the two or four even neighbours at the
+// odd ones; the last odd row and column repeat the edge.  T = float or
+// unsigned char source.
+template <class T>
+__global__ __launch_bounds__(256) void upsample2x_kernel(const T *__restrict__ src, int src_pitch,
+                                                         long src_stride, float *__restrict__ dst,
+                                                         int dst_pitch, long dst_stride, int w, int h)
+{
+    const int X = blockIdx.x * 256 + threadIdx.x, Y = blockIdx.y;
+    if (X >= 2 * w) return;
+    src += blockIdx.z * src_stride;
+    dst += blockIdx.z * dst_stride;
+    const int x0 = X >> 1, y0 = Y >> 1;
+    const int x1 = (X & 1) ? (x0 + 1 < w ? x0 + 1 : x0) : x0;
+    const int y1 = (Y & 1) ? (y0 + 1 < h ? y0 + 1 : y0) : y0;
+    const float a = (float)src[x0 + (long)src_pitch * y0], b = (float)src[x1 + (long)src_pitch * y0];
+    const float c = (float)src[x0 + (long)src_pitch * y1], d = (float)src[x1 + (long)src_pitch * y1];
+    dst[X + (long)dst_pitch * Y] = __fmul_rn(__fadd_rn(__fadd_rn(a, b), __fadd_rn(c, d)), 0.25f);
+}
+
+// ---------------------------------------------------------------------------
 // Gradient sample (gradientKernel cudaSiftD.cu:349-356).  atan2 is evaluated
 // in double with a fixed sequence of IEEE operations and rounded once to
 // float, so the same source gives the same bits on the host.
@@ -1023,8 +1266,8 @@ __device__ __forceinline__ void chain4(const int (&b)[4], const float (&w)[4], f
 
 __global__ __launch_bounds__(64) void keypoint_kernel(
     SiftPointD *pts, long pts_stride, unsigned char *meta, const float *arena, long arena_stride,
-    const unsigned *cand, long cand_stride, const unsigned *counts, long counts_stride,
-    const unsigned *base_count, hl_keypoint_args a)
+    const unsigned *cand, const float4 *sub, long cand_stride, const unsigned *counts,
+    long counts_stride, const unsigned *base_count, hl_keypoint_args a)
 {
     __shared__ float s_mag[REG * REG + 3];
     __shared__ float s_dir[REG * REG + 3];
@@ -1036,6 +1279,7 @@ __global__ __launch_bounds__(64) void keypoint_kernel(
     if (meta) meta += z * pts_stride * 2;
     arena += z * arena_stride;
     cand += z * cand_stride;
+    if (sub) sub += z * cand_stride;
     counts += z * counts_stride;
     const unsigned base = base_count[z];
     const unsigned cap = (unsigned)a.cap;
@@ -1055,9 +1299,15 @@ __global__ __launch_bounds__(64) void keypoint_kernel(
         if (g < 0) break;
         const unsigned local = j - start;
         const int oi = g / a.n_scales;
-        const int si = g - oi * a.n_scales;
+        int si = g - oi * a.n_scales;
         const hl_octave oc = a.oct[oi];
         const unsigned xy = cand[(long)g * cap + local];
+        // "lowe" profile: position, scale and the plane the point ended on come refined
+        float4 rf = float4{0.f, 0.f, 0.f, 0.f};
+        if (sub) {
+            rf = sub[(long)g * cap + local];
+            si = __float_as_int(rf.w) - 1;
+        }
         const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
         const int w = oc.w, h = oc.h, p = oc.p;
         const float *bl = arena + oc.blur_off + (long)(si + 1) * p * h; // blur plane si+1
@@ -1216,9 +1466,9 @@ __global__ __launch_bounds__(64) void keypoint_kernel(
         out->data[lane] = hv[0];
         out->data[lane + 64] = hv[1];
         if (lane == 0) {
-            out->xpos = (float)x;
-            out->ypos = (float)y;
-            out->scale = a.scale_value[g];
+            out->xpos = sub ? rf.x : (float)x;
+            out->ypos = sub ? rf.y : (float)y;
+            out->scale = sub ? rf.z : a.scale_value[g];
             out->orientation = orientation;
             if (meta) {
                 meta[2 * (base + j)] = (unsigned char)(a.first_octave + oi);
@@ -1226,6 +1476,15 @@ __global__ __launch_bounds__(64) void keypoint_kernel(
             }
         }
     }
+}
+
+// 8-bit descriptors: min(255, round-half-up(512 v)), 128 per point
+__global__ __launch_bounds__(128) void quantize_kernel(const SiftPointD *pts, int n, unsigned char *out)
+{
+    const int j = blockIdx.x;
+    if (j >= n) return;
+    const float q = floorf(__fadd_rn(__fmul_rn(pts[j].data[threadIdx.x], 512.0f), 0.5f));
+    out[128L * j + threadIdx.x] = (unsigned char)(q > 255.0f ? 255.0f : q);
 }
 
 __global__ void finalize_counts_kernel(unsigned *base_count, const unsigned *counts,
@@ -1494,7 +1753,7 @@ int hl_pyramid(const void *src, int src_w, int src_h, int src_pitch, long src_st
                float *blur, long blur_stride, int w, int p, int h,
                int n_scales, int nimg, const hl_taps *taps, float contrast, unsigned *queue,
                long queue_stride, unsigned *qcount, long qcount_stride, int qcap, int group0,
-               void *stream)
+               int plain, void *stream)
 {
     if (w <= 0 || h <= 0 || nimg <= 0 || !src || !blur || src_pitch < src_w) return -1001;
     if (p < w || (p & 63)) return -1005; // all 64 lanes of a block store: the pitch must cover them
@@ -1522,7 +1781,7 @@ int hl_pyramid(const void *src, int src_w, int src_h, int src_pitch, long src_st
 #define PYR_LAUNCH(SS, MD)                                                                         \
     hipLaunchKernelGGL((pyramid_kernel<SS, MD>), grid, block, 0, s, (const float *)src, src_w,     \
                        src_h, src_pitch, src_stride, blur, blur_stride, w, p, h, rows, *taps,      \
-                       contrast, queue, queue_stride, qcount, qcount_stride, qcap, group0)
+                       contrast, queue, queue_stride, qcount, qcount_stride, qcap, group0, plain)
     if (n_scales != 2 && n_scales != 3) return -1002;
     switch (src_mode + 3 * (n_scales - 2)) {
     case 0: PYR_LAUNCH(2, 0); break;
@@ -1604,10 +1863,71 @@ int hl_detect(const float *arena, long arena_stride, unsigned *cand, long cand_s
     return launch_status();
 }
 
+int hl_verify_lowe(const float *arena, long arena_stride, const unsigned *queue, long queue_stride,
+                   const unsigned *qcount, long qcount_stride, unsigned *cand, void *sub,
+                   long cand_stride, unsigned *counts, long counts_stride, const hl_detect_args *a,
+                   int nimg, void *stream)
+{
+    if (!detect_args_ok(a, nimg) || !sub) return -1001;
+    dim3 grid(8, a->n_oct * a->n_scales, nimg), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    ScopedTimer t(5, s);
+    if (a->n_scales == 2)
+        hipLaunchKernelGGL((verify_lowe_kernel<2>), grid, block, 0, s, arena, arena_stride, queue,
+                           queue_stride, qcount, qcount_stride, cand, (float4 *)sub, cand_stride,
+                           counts, counts_stride, *a);
+    else
+        hipLaunchKernelGGL((verify_lowe_kernel<3>), grid, block, 0, s, arena, arena_stride, queue,
+                           queue_stride, qcount, qcount_stride, cand, (float4 *)sub, cand_stride,
+                           counts, counts_stride, *a);
+    return launch_status();
+}
+
+int hl_detect_lowe(const float *arena, long arena_stride, unsigned *cand, void *sub, long cand_stride,
+                   unsigned *counts, long counts_stride, const unsigned *gate, long gate_stride,
+                   const hl_detect_args *a, int nimg, void *stream)
+{
+    if (!detect_args_ok(a, nimg) || !sub) return -1001;
+    const int gx = gate ? 32 : (a->dense0[a->n_oct] < 4096 ? a->dense0[a->n_oct] : 4096);
+    dim3 grid(gx, 1, nimg), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    ScopedTimer t(2, s);
+    if (a->n_scales == 2)
+        hipLaunchKernelGGL((detect_lowe_kernel<2>), grid, block, 0, s, arena, arena_stride, cand,
+                           (float4 *)sub, cand_stride, counts, counts_stride, gate, gate_stride, *a);
+    else
+        hipLaunchKernelGGL((detect_lowe_kernel<3>), grid, block, 0, s, arena, arena_stride, cand,
+                           (float4 *)sub, cand_stride, counts, counts_stride, gate, gate_stride, *a);
+    return launch_status();
+}
+
+int hl_upsample2x(const void *src, int src_u8, int src_pitch, long src_stride, float *dst, int dst_pitch,
+                  long dst_stride, int w, int h, int nimg, void *stream)
+{
+    if (!src || !dst || w < 1 || h < 1 || nimg < 1 || src_pitch < w || dst_pitch < 2 * w) return -1001;
+    dim3 grid(idivup(2 * w, 256), 2 * h, nimg), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (src_u8)
+        hipLaunchKernelGGL((upsample2x_kernel<unsigned char>), grid, block, 0, s, (const unsigned char *)src,
+                           src_pitch, src_stride, dst, dst_pitch, dst_stride, w, h);
+    else
+        hipLaunchKernelGGL((upsample2x_kernel<float>), grid, block, 0, s, (const float *)src, src_pitch,
+                           src_stride, dst, dst_pitch, dst_stride, w, h);
+    return launch_status();
+}
+
+int hl_quantize(const void *pts, int n, unsigned char *out, void *stream)
+{
+    if (!pts || !out || n < 0) return -1001;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(quantize_kernel, dim3(n), dim3(128), 0, (hipStream_t)stream, (const SiftPointD *)pts, n, out);
+    return launch_status();
+}
+
 int hl_keypoints(void *pts, long pts_stride_points, unsigned char *meta, const float *arena,
-                 long arena_stride, const unsigned *cand, long cand_stride, const unsigned *counts,
-                 long counts_stride, const unsigned *base_count, const hl_keypoint_args *args,
-                 int nimg, void *stream)
+                 long arena_stride, const unsigned *cand, const void *sub, long cand_stride,
+                 const unsigned *counts, long counts_stride, const unsigned *base_count,
+                 const hl_keypoint_args *args, int nimg, void *stream)
 {
     if (nimg <= 0 || args->n_groups <= 0 || args->n_groups > HL_MAX_GROUPS) return -1001;
     // one wave per keypoint, grid-stride: the count is only known on the device
@@ -1617,8 +1937,8 @@ int hl_keypoints(void *pts, long pts_stride_points, unsigned char *meta, const f
     hipStream_t s = (hipStream_t)stream;
     ScopedTimer t(3, s);
     hipLaunchKernelGGL(keypoint_kernel, grid, block, 0, s, (SiftPointD *)pts, pts_stride_points, meta,
-                       arena, arena_stride, cand, cand_stride, counts, counts_stride, base_count,
-                       *args);
+                       arena, arena_stride, cand, (const float4 *)sub, cand_stride, counts, counts_stride,
+                       base_count, *args);
     return launch_status();
 }
 

@@ -328,3 +328,65 @@ def test_host_pipeline_writes_the_oracles_text_files(sift, oracle_mod, tmp_path)
                 assert len(got) == len(want) - 1 and set(got) <= set(want)
             else:
                 assert sorted(got) == sorted(want)
+
+
+def test_large_8k_image_against_oracle(sift, oracle_mod):
+    """One dense 7680x4320 image, 6 octaves, cap 2^20: 31 k keypoints.  The first octave's
+    candidate queues overflow at this size, so the dense detector takes those groups over while
+    the later octaves stay on the queue path."""
+    pr = _params(sift, oracle_mod, n_scales=2, n_octaves=6, max_points=1 << 20)
+    w, h = 7680, 4320
+    img = sift.synth_image(w, h, seed=9000, dense=True)
+    ref, meta, total = oracle_mod.extract(pr, img, w)
+    assert total == len(ref) > 30000 and (meta[:, 0] == 1).sum() > 1000
+    got = _extract_gpu(sift, img, w)
+    _assert_points_equal(oracle_mod, got, ref)
+    sift.shutdown()  # give the 1.2 GB of arena and lists back before the next test
+
+
+@pytest.mark.parametrize(
+    "w,h,S,O,seed,up,qcap",
+    [(640, 480, 2, 4, 1, 0, 65536), (333, 250, 3, 3, 2, 0, 65536), (400, 300, 2, 3, 3, 1, 65536),
+     (257, 190, 3, 2, 4, 1, 65536), (640, 480, 2, 4, 5, 0, 0), (640, 480, 2, 4, 5, 0, 500)],
+)
+def test_profile_lowe_matches_oracle(sift, oracle_mod, w, h, S, O, seed, up, qcap):
+    """Profile "lowe" (strict extrema, refinement, rejection; optionally an up-sampled first
+    octave): no counterpart in the reference, so the oracle's definition is the only pin.  Bit
+    for bit, through the queue path, the dense path (queue capacity 0) and a mix (500)."""
+    kw = dict(n_scales=S, n_octaves=O, max_points=30000, profile=1, upsample=up)
+    pr = _params(sift, oracle_mod, **kw)
+    img = sift.synth_image(w, h, seed=seed, dense=True)
+    ref, meta, total = oracle_mod.extract(pr, img, w)
+    assert total == len(ref) > 200
+    frac = np.abs(ref["xpos"] * (2.0 if up else 1.0) % 1.0)
+    assert (frac > 0).mean() > 0.9, "positions are refined, not integers"
+    sift.lib().sift_set_queue_cap(qcap)
+    try:
+        got = _extract_gpu(sift, img, w)
+    finally:
+        sift.lib().sift_set_queue_cap(65536)
+        sift.set_params()
+    _assert_points_equal(oracle_mod, got, ref)
+
+
+def test_profile_lowe_batch_u8_and_quantized_descriptors(sift, oracle_mod):
+    pr = _params(sift, oracle_mod, n_scales=2, n_octaves=4, max_points=6000, profile=1, upsample=1)
+    n, w, h = 3, 320, 240
+    imgs = np.stack([sift.synth_image(w, h, seed=40 + i, dense=True) for i in range(n)])
+    try:
+        d_pts, counts, meta = sift.extract_batch(torch.from_numpy(imgs.astype(np.uint8)).cuda(), w, want_meta=True)
+        q = sift.quantize_descriptors(d_pts, int(counts[0])).cpu().numpy()
+    finally:
+        sift.set_params()
+    meta = meta.cpu().numpy().reshape(n, pr.max_points, 2)
+    for i in range(n):
+        ref, rmeta, total = oracle_mod.extract(pr, imgs[i], w)
+        assert total == len(ref) == counts[i] > 100
+        got = sift.points_to_numpy(d_pts, int(counts[i]), offset=i * pr.max_points)
+        _assert_points_equal(oracle_mod, got, ref)
+        # meta = (octave index in the processed pyramid, scale index the point ended on)
+        key = lambda p, m: sorted(zip(p["scale"].tolist(), p["ypos"].tolist(), p["xpos"].tolist(), m[:, 0].tolist(), m[:, 1].tolist()))
+        assert key(got, meta[i, : counts[i]]) == key(ref, rmeta)
+    got0 = sift.points_to_numpy(d_pts, int(counts[0]))
+    assert np.array_equal(q, oracle_mod.quantize_descriptors(got0))
+    assert q.max() <= 255 and q.max() > 50

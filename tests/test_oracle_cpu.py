@@ -251,3 +251,58 @@ def test_text_format(oracle_mod):
     vals = head[4].split(" ")
     assert len(vals) == 129 and vals[-1] == "" and vals[:3] == ["0.200000", "0.012346", "0.000000"]
     assert lines[1].startswith("300.0\t41.0\t2.263\t348.750\t")
+
+
+# ---- profile "lowe": known answers for the parts the reference does not have ----
+def test_det_exp2_is_two_to_the_f(oracle_mod):
+    for f in np.linspace(-1.0, 2.0, 61):
+        assert abs(oracle_mod.det_exp2(float(f)) - 2.0 ** f) < 4e-16 * 2.0 ** f
+    assert oracle_mod.det_exp2(0.0) == 1.0
+
+
+def test_upsample2x_known_answers(oracle_mod):
+    img = np.arange(12, dtype=np.float32).reshape(3, 4) * 2
+    up = oracle_mod.upsample2x(img)
+    assert up.shape == (6, 8)
+    assert np.array_equal(up[::2, ::2], img)
+    assert np.array_equal(up[::2, 1:-1:2], (img[:, :-1] + img[:, 1:]) / 2)
+    assert np.array_equal(up[1:-1:2, ::2], (img[:-1] + img[1:]) / 2)
+    assert np.array_equal(up[:, -1], up[:, -2]) and np.array_equal(up[-1], up[-2])
+
+
+def test_lowe_refinement_recovers_a_subpixel_blob_centre(oracle_mod):
+    """A Gaussian blob centred between samples: the refined position is within 0.08 pixels of its
+    octave's grid of the centre (0.07 input pixels at the finest octave that finds it), with and
+    without the up-sampled octave, and the reported scale follows the blob's size."""
+    w, h = 200, 160
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    for cx, cy, sb in [(100.3, 80.7, 3.0), (90.55, 70.2, 5.0), (120.1, 66.45, 4.0)]:
+        img = (128 + 80 * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * sb * sb))).astype(np.float32)
+        scales = []
+        for up in (0, 1):
+            pr = oracle_mod.params(n_octaves=3, n_scales=2, max_points=100, profile=1, upsample=up)
+            pts, meta, total = oracle_mod.extract(pr, img, w)
+            assert 1 <= total == len(pts) <= 3
+            pix = 2.0 ** meta[:, 0].astype(np.float64) * (0.5 if up else 1.0)  # input pixels per octave pixel
+            assert np.all(np.abs(pts["xpos"] - cx) < 0.08 * pix) and np.all(np.abs(pts["ypos"] - cy) < 0.08 * pix)
+            assert np.abs(pts["xpos"] - cx).min() < 0.07 and np.abs(pts["ypos"] - cy).min() < 0.07
+            scales += pts["scale"].tolist()
+        assert min(scales) > 0.5 * sb and max(scales) < 1.5 * sb
+
+
+def test_lowe_rejects_edges_and_flat_images(oracle_mod):
+    w, h = 160, 120
+    pr = oracle_mod.params(n_octaves=3, n_scales=2, max_points=100, profile=1)
+    flat = np.full((h, w), 77, np.float32)
+    assert oracle_mod.extract(pr, flat, w)[2] == 0
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    ridge = (128 + 90 * np.exp(-((xx - 80.3) ** 2) / (2 * 3.0 ** 2))).astype(np.float32)  # a vertical line
+    assert oracle_mod.extract(pr, ridge, w)[2] == 0
+
+
+def test_quantized_descriptors(oracle_mod):
+    pts = np.zeros(2, oracle_mod.POINT_DTYPE)
+    pts["data"][0, :4] = [0.0, 0.2, 1.0 / 512, 0.5 / 512]
+    pts["data"][1, :] = 1.0
+    q = oracle_mod.quantize_descriptors(pts)
+    assert q[0, :4].tolist() == [0, 102, 1, 1] and np.all(q[1] == 255)
