@@ -170,6 +170,13 @@ int sift_save_points(const char *dst_dir, const char *src_path, const SiftPoint 
 int sift(const char *dst_dir, const char **src_paths, int n_imgs);
 /* the reference hands count-1 to its writer (sift.cu:125); 1 reproduces that */
 void sift_pipeline_drop_last_point(int on);
+/* Visual check (image::drawPoint is declared at utils.h:32 and never defined):
+ * writes a binary PPM of the grey image with a circle of radius 3*scale and an
+ * orientation spoke per point.  point_pos_scale (optional, one per point) maps
+ * point coordinates to image pixels: 2^octave for profile ref, NULL (= 1) for
+ * profile lowe.  Host memory throughout.  Returns 0 or -1. */
+int sift_draw_points(const char *path, const float *gray, int w, int pitch, int h,
+                     const SiftPoint *pts, int n, const float *point_pos_scale);
 
 /* ---- measurement hooks ---------------------------------------------------- */
 enum {

@@ -90,6 +90,7 @@ SYMBOLS = {
     "sift_format_points": (C.c_long, [_vp, C.c_int, C.c_char_p, C.c_long]),
     "sift_save_points": (C.c_int, [C.c_char_p, C.c_char_p, _vp, C.c_int]),
     "sift": (C.c_int, [C.c_char_p, C.POINTER(C.c_char_p), C.c_int]),
+    "sift_draw_points": (C.c_int, [C.c_char_p, _fp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _fp]),
     "sift_pipeline_drop_last_point": (None, [C.c_int]),
     "sift_timing_enable": (None, [C.c_int]),
     "sift_timing_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]),

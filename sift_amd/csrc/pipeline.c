@@ -6,6 +6,7 @@
 #include "../../include/sift_amd.h"
 
 #include <ctype.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -171,5 +172,60 @@ int sift(const char *dst_dir, const char **src_paths, int n_imgs)
         }
         done += nq;
     }
+    return rc;
+}
+
+/* ---- visualisation ------------------------------------------------------------
+ * The reference declares image::drawPoint (utils.h:32) and never defines it.
+ * Keypoints are drawn into a colour copy of the grey image: a circle of radius
+ * 3*scale around (xpos, ypos) and a spoke along the orientation, written as a
+ * binary PPM.  pos_scale maps point coordinates to image pixels (1 for profile
+ * lowe, whose positions are input pixels; for profile ref a point of octave o
+ * lives on a grid 2^o times coarser, which the caller knows from the meta array
+ * and passes per point through point_pos_scale when it is not NULL). */
+static void put_px(unsigned char *rgb, int w, int h, int x, int y, const unsigned char c[3])
+{
+    if (x < 0 || x >= w || y < 0 || y >= h) return;
+    unsigned char *p = rgb + 3L * (x + (long)w * y);
+    p[0] = c[0];
+    p[1] = c[1];
+    p[2] = c[2];
+}
+
+int sift_draw_points(const char *path, const float *gray, int w, int pitch, int h,
+                     const SiftPoint *pts, int n, const float *point_pos_scale)
+{
+    if (!path || !gray || w < 1 || h < 1 || pitch < w || n < 0 || (n && !pts)) return -1;
+    unsigned char *rgb = (unsigned char *)malloc(3L * w * h);
+    if (!rgb) return -1;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            float v = gray[x + (long)pitch * y];
+            unsigned char g = (unsigned char)(v < 0.f ? 0.f : (v > 255.f ? 255.f : v + 0.5f));
+            rgb[3L * (x + (long)w * y)] = rgb[3L * (x + (long)w * y) + 1] = rgb[3L * (x + (long)w * y) + 2] = g;
+        }
+    static const unsigned char ring[3] = {255, 40, 40}, spoke[3] = {40, 255, 40};
+    for (int j = 0; j < n; ++j) {
+        const double ps = point_pos_scale ? point_pos_scale[j] : 1.0;
+        const double cx = pts[j].xpos * ps, cy = pts[j].ypos * ps;
+        double r = 3.0 * pts[j].scale;
+        if (r < 2.0) r = 2.0;
+        const int steps = (int)(8.0 * r) + 8;
+        for (int k = 0; k < steps; ++k) {
+            const double a = 6.283185307179586 * k / steps;
+            put_px(rgb, w, h, (int)floor(cx + r * cos(a) + 0.5), (int)floor(cy + r * sin(a) + 0.5), ring);
+        }
+        const double th = pts[j].orientation * 3.141592653589793 / 180.0;
+        for (int k = 0; k <= (int)r; ++k)
+            put_px(rgb, w, h, (int)floor(cx + k * cos(th) + 0.5), (int)floor(cy + k * sin(th) + 0.5), spoke);
+    }
+    FILE *f = fopen(path, "wb");
+    int rc = -1;
+    if (f) {
+        fprintf(f, "P6\n%d %d\n255\n", w, h);
+        if (fwrite(rgb, 3, (size_t)w * h, f) == (size_t)w * h) rc = 0;
+        fclose(f);
+    }
+    free(rgb);
     return rc;
 }

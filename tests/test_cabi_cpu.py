@@ -156,3 +156,29 @@ def test_two_rank_sharding_and_gather_over_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GATHER_OK" in outs[0]
+
+
+def test_draw_points_writes_a_ppm_with_marks(sift, oracle_mod, tmp_path):
+    """sift_draw_points is host code: a grey image, two hand-made points, a PPM out."""
+    C = ctypes
+    w, h = 96, 64
+    gray = np.full((h, w), 100, np.float32)
+    pts = np.zeros(2, oracle_mod.POINT_DTYPE)
+    pts["xpos"], pts["ypos"], pts["scale"], pts["orientation"] = [20, 30], [30, 10], [1.6, 3.2], [0, 90]
+    scale = np.array([1.0, 2.0], np.float32)  # the second point lives on an octave-1 grid
+    out = tmp_path / "marks.ppm"
+    rc = sift.lib().sift_draw_points(os.fsencode(str(out)), gray.ctypes.data_as(C.POINTER(C.c_float)), w, w, h,
+                                     pts.ctypes.data, 2, scale.ctypes.data_as(C.POINTER(C.c_float)))
+    assert rc == 0
+    img = read_pnm(str(out))
+    assert img.shape == (h, w, 3)
+    red = (img[..., 0] == 255) & (img[..., 1] == 40)
+    green = (img[..., 1] == 255) & (img[..., 0] == 40)
+    assert red.sum() > 40 and green.sum() > 8
+    assert green[30, 21] and green[21, 60], "spokes start at the (scaled) positions and follow the orientation"
+    ys, xs = np.nonzero(red)
+    d0 = np.hypot(xs - 20, ys - 30)
+    d1 = np.hypot(xs - 60, ys - 20)
+    assert np.all((np.abs(d0 - 4.8) < 1.0) | (np.abs(d1 - 9.6) < 1.0)), "circles of radius 3*scale"
+    untouched = ~(red | green)
+    assert np.all(img[untouched] == 100)
