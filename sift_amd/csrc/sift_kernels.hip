@@ -1769,10 +1769,13 @@ int hl_pyramid(const void *src, int src_w, int src_h, int src_pitch, long src_st
     // equal in height so that no strip is a short left-over
     int m = 11;
     while (m > 2 && (long)idivup(w, 64) * idivup(h, COL_RING * m - 2 * RADIUS) * nimg < 6144) --m;
+    // a launch that cannot fill the chip anyway (single small images) is bound by
+    // the length of one strip walk: two output rows per strip halve it once more
+    if (m == 2 && (long)idivup(w, 64) * idivup(h, COL_RING * 2 - 2 * RADIUS) * nimg < 1024) m = 1;
     {
         const int n_strips = idivup(h, COL_RING * m - 2 * RADIUS);
         const int m_even = idivup(idivup(h, n_strips) + 2 * RADIUS, COL_RING);
-        if (m_even >= 2 && m_even < m) m = m_even;
+        if (m_even >= 1 && m_even < m) m = m_even;
     }
     const int rows = COL_RING * m - 2 * RADIUS;
     dim3 grid(idivup(w, 64), idivup(h, rows), nimg), block(64);
