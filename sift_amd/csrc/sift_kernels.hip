@@ -5,11 +5,22 @@
 // explicit fmaf()/fma() calls.
 //
 // Kernels (reference counterpart in Sift/src/excludes/cudaSiftD.cu):
-//   row_blur_kernel      xblurMultiKernel :430-486 + tile loader cudaSiftD.h:43-78
-//   col_blur_dog_kernel  yblurKernel :488-534 + subtractKernel :5-15 + resizeKernel :544-559
-//   detect_kernel        findExtremaKernel :216-305 (+ hessianKernel :366-428 at candidates)
-//   keypoint_kernel      gradientKernel :306-364 (in patch) + OrientationKernel :17-94
-//                        + DescriptorKernel :96-214
+//   pyramid_kernel          xblurMultiKernel :430-486 + yblurKernel :488-534 + resizeKernel
+//                           :544-559 in one pass, plus the contrast clause of
+//                           findExtremaKernel :293 as a pre-filter           [the hot path]
+//   alias_prefilter_kernel  the same clause for the pixels whose centre value the reference
+//                           reads through an aliased shared-memory cell :239-261
+//   verify_kernel           findExtremaKernel :216-305 on the queued pixels
+//                           (+ hessianKernel :366-428 at candidates)
+//   detect_kernel           findExtremaKernel over every pixel (fall-back, and the whole
+//                           detector when queues are switched off)
+//   keypoint_kernel         gradientKernel :306-364 (in a patch) + OrientationKernel :17-94
+//                           + DescriptorKernel :96-214
+//   verify_lowe_kernel, detect_lowe_kernel, upsample2x_kernel, quantize_kernel
+//                           profile "lowe": no counterpart in the reference
+//   row_blur_kernel, col_blur_dog_kernel, subtract/hessian/gradient/copy kernels
+//                           the reference's stages one by one (blurOctave, computeDiffOfGauss,
+//                           computeHessian, computeGradient, copyDeviceData cudaSiftH.cu:210-316)
 #include <hip/hip_runtime.h>
 
 #include <mutex>
