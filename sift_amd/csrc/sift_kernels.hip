@@ -269,7 +269,7 @@ __global__ __launch_bounds__(64) void col_blur_dog_kernel(
 //             and even columns (resizeKernel cudaSiftD.cu:544-559 folded into
 //             the fetch; the down-sampled base is never materialised)
 // ---------------------------------------------------------------------------
-constexpr int FZ_PF = 4;
+constexpr int FZ_PF = 2;
 static_assert(20 % FZ_PF == 0, "the prefetch ring must divide the row chunk");
 constexpr int FZ_STAGE = 88; // floats staged per row
 constexpr int PQ_CAP = 1024; // contrast candidates one wave can hold per scale between flushes
