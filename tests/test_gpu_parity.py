@@ -390,3 +390,47 @@ def test_profile_lowe_batch_u8_and_quantized_descriptors(sift, oracle_mod):
     got0 = sift.points_to_numpy(d_pts, int(counts[0]))
     assert np.array_equal(q, oracle_mod.quantize_descriptors(got0))
     assert q.max() <= 255 and q.max() > 50
+
+
+@pytest.mark.parametrize("w,h", [(19, 19), (30, 200), (200, 18), (65, 33), (129, 64)])
+@pytest.mark.parametrize("profile", [0, 1])
+def test_tiny_and_thin_images(sift, oracle_mod, w, h, profile):
+    """Images smaller than the 19-tap support, one strip wide or a few rows tall: every pixel is
+    apron.  Planes and (possibly empty) point lists still equal the oracle's."""
+    pr = _params(sift, oracle_mod, n_scales=2, n_octaves=3, max_points=2000, profile=profile,
+                 extrema_thresh=2.0)
+    img = sift.synth_image(w, h, seed=w * 1000 + h, dense=True)
+    try:
+        ref, _, total = oracle_mod.extract(pr, img, w)
+        assert total == len(ref)
+        got = _extract_gpu(sift, img, w)
+    finally:
+        sift.set_params()
+    _assert_points_equal(oracle_mod, got, ref)
+
+
+def test_full_size_1080p_three_scales(sift, oracle_mod):
+    """1920x1080 with 3 scales and 5 octaves (the S = 3 kernels at full size), one dense image."""
+    pr = _params(sift, oracle_mod, n_scales=3, n_octaves=5, max_points=20000)
+    img = sift.synth_image(1920, 1080, seed=4242, dense=True)
+    try:
+        ref, _, total = oracle_mod.extract(pr, img, 1920)
+        assert total == len(ref) > 2000
+        d_pts, counts = sift.extract_batch(torch.from_numpy(img[None]).cuda(), 1920)
+    finally:
+        sift.set_params()
+    _assert_points_equal(oracle_mod, sift.points_to_numpy(d_pts, int(counts[0])), ref)
+
+
+def test_parameter_validation(sift):
+    with pytest.raises(sift.SiftError):
+        sift.set_params(profile=2)
+    with pytest.raises(sift.SiftError):
+        sift.set_params(profile=0, upsample=1)
+    with pytest.raises(sift.SiftError):
+        sift.set_params(n_scales=4)
+    sift.set_params()
+    assert sift.get_params().profile == 0
+    d = torch.zeros((2, 40, 48), dtype=torch.float64, device="cuda")
+    with pytest.raises(sift.SiftError):
+        sift.extract_batch(d, 48)
