@@ -346,6 +346,12 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     const bool pre_lane = xq > 8 && xq < w - 8 && (plain || xq_tile != 1);
     const bool pre_lane0 = pre_lane && xq_tile == 0; // rows with y mod 32 = 30: see alias_prefilter_kernel
     if (lane < S) lq_n[lane] = 0;
+    // A queue that has already overflowed is lost (the dense detector will redo its
+    // group): strips that start later stop feeding it.
+    float thr[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i)
+        thr[i] = (pre && qcount[z * qcount_stride + group0 + i] > (unsigned)qcap) ? __builtin_inff() : contrast;
 
     // ---- source fetch of one row into registers ----
     // The loads are unconditional (clamped addresses) and pixels outside the
@@ -476,7 +482,7 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
                 const unsigned long long lanes = (!plain && (yo & 31) == 30) ? pre_mask0 : pre_mask;
 #pragma unroll
                 for (int i = 0; i < S; ++i) {
-                    const unsigned long long hits = __ballot(fabsf(__fsub_rn(b[i + 1], b[i + 2])) > contrast) & lanes;
+                    const unsigned long long hits = __ballot(fabsf(__fsub_rn(b[i + 1], b[i + 2])) > thr[i]) & lanes;
                     if (hits) {
                         unsigned base = 0;
                         if (lane == 0) base = atomicAdd(&lq_n[i], (unsigned)__popcll(hits));
@@ -500,10 +506,12 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
             if (n == 0) continue;
             unsigned base = 0;
             if (lane == 0) base = atomicAdd(&qcount[z * qcount_stride + group0 + i], n > PQ_CAP ? (unsigned)qcap + 1u : n);
-            base = __shfl(base, 0);
+            base = __builtin_amdgcn_readfirstlane(__shfl(base, 0));
             if (n <= PQ_CAP)
                 for (unsigned e = lane; e < n; e += 64)
                     if (base + e < (unsigned)qcap) queue[z * queue_stride + (long)i * qcap + base + e] = lq[i][e];
+            // the queue is full: its group goes to the dense detector, stop feeding it
+            if (base + n > (unsigned)qcap) thr[i] = __builtin_inff();
         }
         __syncthreads();
         if (lane < S) lq_n[lane] = 0;
@@ -526,7 +534,10 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     // counter state its own back edge produces, and the waits inside it are
     // exact on every trip.
     chunk(0);
-    for (int rb = COL_RING; rb < nin; rb += COL_RING) chunk(rb);
+    for (int rb = COL_RING; rb < nin; rb += COL_RING) {
+        chunk(rb);
+        flush_if_filling();
+    }
     if (pre) flush();
 }
 
@@ -682,8 +693,6 @@ __device__ __forceinline__ void append_hits(bool hit, unsigned xy, int lane, uns
     }
 }
 
-constexpr int DET_ROWS = 8; // image rows per wave of the dense detector
-
 // The three detection kernels work on all octaves of a launch set at once:
 // blockIdx.y enumerates work units, the octave table says where each octave's
 // units start and where its planes, queues and sizes are.
@@ -726,6 +735,11 @@ __global__ __launch_bounds__(256) void alias_prefilter_kernel(const float *__res
     queue += z * queue_stride + oc.queue_off;
     qcount += z * qcount_stride + oi * S;
     const bool in_x = xs4 < w;
+    // a queue that has overflowed belongs to the dense detector: nothing more is added
+    // (the test is folded into the hit so that the loads of all scales stay independent)
+    bool live[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) live[i] = qcount[i] <= (unsigned)oc.qcap;
 
 #pragma unroll
     for (int i = 0; i < S; ++i) {
@@ -752,7 +766,7 @@ __global__ __launch_bounds__(256) void alias_prefilter_kernel(const float *__res
                 const int yt = t == 0 ? yA + 31 : (t == 1 ? yA + 32 : yC + 31);
                 const int xm = xt % XT_DATAX;
                 const bool col_ok = t == 1 ? (xs >= 64 && xm < XT_BDIM) : (xm >= 2 * XT_BDIM);
-                const bool hit = xs < w && col_ok && xt > 8 && xt < w - 8 && yt > 8 && yt < h - 8 &&
+                const bool hit = live[i] && xs < w && col_ok && xt > 8 && xt < w - 8 && yt > 8 && yt < h - 8 &&
                                  fabsf(v) > a.contrast;
                 append_hits(hit, (unsigned)xt | ((unsigned)yt << 16), lane, &qcount[i],
                             queue + (long)i * oc.qcap, oc.qcap);
@@ -833,13 +847,39 @@ __global__ __launch_bounds__(256) void verify_kernel(const float *__restrict__ a
     if (pending) run_slow(0, pending);
 }
 
-// Dense detector.  One wave per 256-pixel wide, 8-row tall block of pixels,
-// four pixels per lane and row (one 16-byte load per centre plane and row, all
-// issued before the first use).  The contrast test runs first; survivors go
-// through a per-wave LDS queue so that a cluster of them is spread over all 64
-// lanes before the rank and edge tests.  With `gate` set a group is processed
-// only if its queue counter overflowed (gate[group] > qcap): the fall-back
-// behind the pre-filters.  With gate NULL it is the whole detector.
+// Dense detector: the reference's kernel as it stands.  One block per 96 x 32
+// pixels loads the three DoG tiles (101 x 34 floats each, 98 columns written,
+// zero outside the image) into LDS at the reference's spacing of 3168 floats,
+// in its order, so a later tile overwrites the tail of the one before exactly
+// as it does there (cudaSiftD.cu:239-261).  The rank is then read straight out
+// of LDS (cudaSiftD.cu:271-284), with the carry over the three 32-wide column
+// tiles.  The contrast test runs first and only the left and right column tiles
+// are looked at (the middle one can never reach rank 9).  Cost is a streaming
+// read of the planes whatever the number of candidates, which is what makes it
+// the right tool when a queue overflows.  With `gate` set a group is processed
+// only if its queue counter overflowed (gate[group] > qcap); with gate NULL it
+// is the whole detector.
+constexpr int XT_TILE = XT_SDIMX * 34; // cells of one tile
+
+__device__ __forceinline__ bool edge_ok(const float *__restrict__ b, int p, float edge_limit)
+{
+    // hessianKernel cudaSiftD.cu:405-419 on blur plane i+1, then cudaSiftD.cu:287-292
+    const float c = b[0];
+    float Dxx = -2.f * c;
+    Dxx += b[-1];
+    Dxx += b[1];
+    float Dyy = -2.f * c;
+    Dyy += b[-p];
+    Dyy += b[p];
+    float Dxy = c;
+    Dxy += b[-p - 1];
+    Dxy -= b[-1];
+    Dxy -= b[-p];
+    const float trace = Dxx + Dyy;
+    const float det = Dxx * Dyy + Dxy * Dxy; // PLUS, and no contraction (cudaSiftD.cu:288)
+    return (trace * trace) / det < edge_limit;
+}
+
 template <int S>
 __global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ arena, long arena_stride,
                                                      unsigned *cand, long cand_stride,
@@ -847,10 +887,11 @@ __global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ a
                                                      const unsigned *gate, long gate_stride,
                                                      hl_detect_args a)
 {
-    __shared__ unsigned q_xy[4][DET_ROWS * 256];
-    __shared__ unsigned q_n[4];
+    __shared__ float sh[2 * XT_PLANE_OFF + XT_TILE + 2];
+    // pixels of the block that passed the contrast test: (tile << 16 | ty << 8 | tx)
+    __shared__ unsigned hot[2 * XT_BDIM * XT_BDIM];
+    __shared__ unsigned hot_n;
     const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
     const int z = blockIdx.z;
     cand += z * cand_stride;
     counts += z * counts_stride;
@@ -860,73 +901,91 @@ __global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ a
         for (int g = 0; g < a.n_oct * S; ++g) any = any || gate[g] > (unsigned)a.oct[g / S].qcap;
         if (!any) return; // block-uniform
     }
-    // dense0[] counts blocks of 256 x 32 pixels, octave after octave, row-major
+    constexpr int CELLS = XT_WRITTEN * 34;          // cells of a tile that are written
+    constexpr int ROUNDS = (CELLS + 255) / 256;     // per thread
+    // dense0[] counts blocks of 96 x 32 pixels, octave after octave, row-major
     for (int unit = blockIdx.x; unit < a.dense0[a.n_oct]; unit += gridDim.x) {
         const int oi = find_octave(a.dense0, a.n_oct, unit);
         const hl_octave oc = a.oct[oi];
         const int w = oc.w, h = oc.h, p = oc.p;
-        const int xblocks = (w + 255) / 256;
+        const int xblocks = (w + XT_DATAX - 1) / XT_DATAX;
         const int u = unit - a.dense0[oi];
-        const int x4 = (u % xblocks) * 256 + 4 * lane;
-        const int y0 = ((u / xblocks) * 4 + wv) * DET_ROWS;
+        const int bx = u % xblocks, by = u / xblocks;
         const long plane = (long)p * h;
         const float *blur = arena + z * arena_stride + oc.blur_off;
-        // 96 and 32 are multiples of 4, so the four pixels of a lane share a tile;
-        // a pixel in the middle tile can never reach rank 9
-        const int tile = (x4 % XT_DATAX) / XT_BDIM;
-        const bool lane_ok = x4 < w && tile != 1;
-
-#pragma unroll
+#pragma unroll 1
         for (int i = 0; i < S; ++i) {
             const int g = oi * S + i;
             if (gate && gate[g] <= (unsigned)oc.qcap) continue; // block-uniform
             const float *b3 = blur + i * plane; // blur planes i..i+3: DoG planes i..i+2
-            if (lane == 0) q_n[wv] = 0;
-            float v[DET_ROWS][4];
+            // every cell's four blur values are requested before the first is used:
+            // one memory round trip for the three tiles
+            float v[ROUNDS][4];
 #pragma unroll
-            for (int r = 0; r < DET_ROWS; ++r) {
-                const int y = y0 + r;
-                const bool ok = lane_ok && y > 8 && y < h - 8; // cudaSiftD.cu:289-290
-                if ((y & 31) < 30) { // wave-uniform
-                    const float *c = b3 + plane + (ok ? x4 + (long)p * y : 0);
-                    const float4 t = *reinterpret_cast<const float4 *>(c);
-                    const float4 u = *reinterpret_cast<const float4 *>(c + plane);
-                    v[r][0] = __fsub_rn(t.x, u.x);
-                    v[r][1] = __fsub_rn(t.y, u.y);
-                    v[r][2] = __fsub_rn(t.z, u.z);
-                    v[r][3] = __fsub_rn(t.w, u.w);
-                } else { // the centre value itself is read through an aliased cell
+            for (int it = 0; it < ROUNDS; ++it) {
+                const int c = min((int)threadIdx.x + 256 * it, CELLS - 1);
+                const int sy = c / XT_WRITTEN, sx = c - sy * XT_WRITTEN;
+                const int x = XT_DATAX * bx - 1 + sx, y = XT_BDIM * by - 1 + sy;
+                const bool in = x >= 0 && x < w && y >= 0 && y < h;
+                const float *q = b3 + (in ? x + (long)p * y : 0);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        v[r][q] = center_value(b3, plane, w, p, h, ok ? min(x4 + q, w - 1) : 0, ok ? y : 0);
+                for (int k = 0; k < 4; ++k) v[it][k] = q[k * plane];
+            }
+            __syncthreads(); // readers of the previous tiles are done
+            if (threadIdx.x == 0) hot_n = 0;
+            for (int t = 0; t < 3; ++t) {
+#pragma unroll
+                for (int it = 0; it < ROUNDS; ++it) {
+                    const int c = threadIdx.x + 256 * it;
+                    const int sy = c / XT_WRITTEN, sx = c - sy * XT_WRITTEN;
+                    const int x = XT_DATAX * bx - 1 + sx, y = XT_BDIM * by - 1 + sy;
+                    const bool in = x >= 0 && x < w && y >= 0 && y < h;
+                    if (c < CELLS) sh[t * XT_PLANE_OFF + sx + XT_SDIMX * sy] = in ? __fsub_rn(v[it][t], v[it][t + 1]) : 0.f;
+                }
+                __syncthreads(); // the next tile overwrites the tail of this one
+            }
+            // contrast test first: the survivors are listed, then shared out over the block
+            const int tx = threadIdx.x & 31;
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int ty = pass * 8 + (threadIdx.x >> 5);
+                const int y = XT_BDIM * by + ty;
+#pragma unroll
+                for (int tile = 0; tile < 3; tile += 2) {
+                    const int x = XT_DATAX * bx + tx + XT_BDIM * tile;
+                    const float pv = sh[XT_PLANE_OFF + 1 + tx + XT_BDIM * tile + XT_SDIMX * (1 + ty)];
+                    if (x > 8 && x < w - 8 && y > 8 && y < h - 8 && fabsf(pv) > a.contrast)
+                        hot[atomicAdd(&hot_n, 1u)] = (unsigned)tx | ((unsigned)ty << 8) | ((unsigned)tile << 16);
                 }
             }
             __syncthreads();
-#pragma unroll
-            for (int r = 0; r < DET_ROWS; ++r) {
-                const int y = y0 + r;
-                const bool ok = lane_ok && y > 8 && y < h - 8;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (ok && x4 + q > 8 && x4 + q < w - 8 && fabsf(v[r][q]) > a.contrast) {
-                        const unsigned slot = atomicAdd(&q_n[wv], 1u);
-                        q_xy[wv][slot] = (unsigned)(x4 + q) | ((unsigned)y << 16);
-                    }
-            }
-            __syncthreads();
-            const unsigned nq = q_n[wv];
-            for (unsigned e0 = 0; e0 < nq; e0 += 64) { // wave-uniform trip count
-                const unsigned e = e0 + lane;
+            const unsigned n_hot = hot_n;
+            for (unsigned e0 = 0; e0 < n_hot; e0 += 256) { // block-uniform trip count
+                const unsigned e = e0 + threadIdx.x;
                 bool hit = false;
                 unsigned xy = 0;
-                if (e < nq) {
-                    xy = q_xy[wv][e];
-                    hit = accept_candidate<false>(b3, plane, w, p, h, a.edge_limit, (int)(xy & 0xffffu),
-                                           (int)(xy >> 16));
+                if (e < n_hot) {
+                    const unsigned hv = hot[e];
+                    const int htx = hv & 0xff, hty = (hv >> 8) & 0xff, tile = hv >> 16;
+                    const int sy = 1 + hty;
+                    int r = 0;
+                    for (int tt = 0; tt <= tile; ++tt) { // the reference never resets its rank between tiles
+                        const int sx = 1 + htx + XT_BDIM * tt;
+                        const float cv = sh[XT_PLANE_OFF + sx + XT_SDIMX * sy];
+#pragma unroll
+                        for (int l = -1; l < 2; ++l)
+#pragma unroll
+                            for (int m = -1; m < 2; ++m)
+#pragma unroll
+                                for (int k = 0; k < 3; ++k)
+                                    r += (cv >= sh[k * XT_PLANE_OFF + sx + l + XT_SDIMX * (sy + m)]) ? 1 : -1;
+                    }
+                    const int x = XT_DATAX * bx + htx + XT_BDIM * tile, y = XT_BDIM * by + hty;
+                    xy = (unsigned)x | ((unsigned)y << 16);
+                    hit = r == 9 && edge_ok(b3 + plane + x + (long)p * y, p, a.edge_limit);
                 }
                 append_hits(hit, xy, lane, &counts[g], cand + (long)g * a.cap, a.cap);
             }
-            __syncthreads();
         }
     }
 }
@@ -1102,7 +1161,7 @@ __global__ __launch_bounds__(256) void verify_lowe_kernel(
 }
 
 // Dense form of the same detector, for the groups whose queue overflowed (gate)
-// or for everything (gate NULL).  A block walks over 256 x 32 pixel units.
+// or for everything (gate NULL).  A block walks over 96 x 32 pixel units.
 template <int S>
 __global__ __launch_bounds__(256) void detect_lowe_kernel(
     const float *__restrict__ arena, long arena_stride, unsigned *cand, float4 *sub, long cand_stride,
@@ -1123,9 +1182,9 @@ __global__ __launch_bounds__(256) void detect_lowe_kernel(
         const int oi = find_octave(a.dense0, a.n_oct, unit);
         const hl_octave oc = a.oct[oi];
         const int w = oc.w, h = oc.h, p = oc.p;
-        const int xblocks = (w + 255) / 256;
+        const int xblocks = (w + XT_DATAX - 1) / XT_DATAX; // the units are the dense detector's 96 x 32 blocks
         const int u = unit - a.dense0[oi];
-        const int x = (u % xblocks) * 256 + threadIdx.x;
+        const int x = threadIdx.x < XT_DATAX ? (u % xblocks) * XT_DATAX + threadIdx.x : w;
         const int yb = (u / xblocks) * 32;
         const long plane = (long)p * h;
         const float *blur0 = arena + z * arena_stride + oc.blur_off;
@@ -1862,9 +1921,14 @@ int hl_detect(const float *arena, long arena_stride, unsigned *cand, long cand_s
               const hl_detect_args *a, int nimg, void *stream)
 {
     if (!detect_args_ok(a, nimg) || (arena_stride & 3) || (((size_t)arena) & 15)) return -1001;
-    // with a gate the kernel normally has nothing to do: few blocks, each walking
-    // over the units; without one it is the whole detector and fills the chip
-    const int gx = gate ? 32 : (a->dense0[a->n_oct] < 4096 ? a->dense0[a->n_oct] : 4096);
+    // with a gate the kernel normally has nothing to do: few blocks per image, each
+    // walking over the units; without one it is the whole detector and fills the chip
+    int gx = a->dense0[a->n_oct] < 4096 ? a->dense0[a->n_oct] : 4096;
+    if (gate) {
+        int per_image = 8192 / nimg;
+        per_image = per_image < 32 ? 32 : (per_image > 1024 ? 1024 : per_image);
+        if (gx > per_image) gx = per_image;
+    }
     dim3 grid(gx, 1, nimg), block(256);
     hipStream_t s = (hipStream_t)stream;
     ScopedTimer t(2, s);
