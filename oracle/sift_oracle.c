@@ -87,37 +87,36 @@ void oracle_rotation_table(float *c32, float *s32)
  * The reference calls the CUDA device atan2f (cudaSiftD.cu:356), which is not
  * available.  This evaluation uses only IEEE double +,-,*,/ and fma in a fixed
  * order, so the same source gives the same bits on any IEEE machine; the
- * double result (rel. error < 1e-13) is rounded once to float. */
-static double atan_small(double t) /* |t| <= tan(pi/8) */
+ * double result (rel. error < 1e-15) is rounded once to float.
+ * With a = min/max of |x|,|y| and c the nearest of 0, 1/4, 1/2, 3/4, 1:
+ * atan(a) = atan(c) + atan(t), t = (a - c)/(1 + a c) = (min - c max)/(max + c min),
+ * |t| < 0.1245, so one division and a series up to t^17 suffice. */
+static double atan_small(double t) /* |t| < 1/8 */
 {
-    static const double C[17] = {
-        -1.0 / 3.0,  1.0 / 5.0,  -1.0 / 7.0,  1.0 / 9.0,  -1.0 / 11.0, 1.0 / 13.0,
-        -1.0 / 15.0, 1.0 / 17.0, -1.0 / 19.0, 1.0 / 21.0, -1.0 / 23.0, 1.0 / 25.0,
-        -1.0 / 27.0, 1.0 / 29.0, -1.0 / 31.0, 1.0 / 33.0, -1.0 / 35.0};
+    static const double C[8] = {-1.0 / 3.0, 1.0 / 5.0,  -1.0 / 7.0,  1.0 / 9.0,
+                                -1.0 / 11.0, 1.0 / 13.0, -1.0 / 15.0, 1.0 / 17.0};
     double s = t * t;
-    double q = C[16];
-    for (int k = 15; k >= 0; --k)
+    double q = C[7];
+    for (int k = 6; k >= 0; --k)
         q = fma(q, s, C[k]);
     return fma(t * s, q, t);
 }
 
 float oracle_atan2f(float yf, float xf)
 {
+    static const double ATAN_C[5] = {0.0, 0.24497866312686414, 0.46364760900080609,
+                                     0.64350110879328437, 0.78539816339744831};
     double x = (double)xf, y = (double)yf;
     double ax = fabs(x), ay = fabs(y);
     double mx = ax > ay ? ax : ay;
     double mn = ax > ay ? ay : ax;
-    double r;
-    if (mx == 0.0) {
-        r = 0.0;
-    } else {
-        double a = mn / mx;
-        if (a > 0.41421356237309503) {
-            double t = (a - 1.0) / (a + 1.0);
-            r = 0.78539816339744831 + atan_small(t);
-        } else {
-            r = atan_small(a);
-        }
+    double r = 0.0;
+    if (mx != 0.0) {
+        const double m8 = 8.0 * mn;
+        const int j = (m8 >= mx) + (m8 >= 3.0 * mx) + (m8 >= 5.0 * mx) + (m8 >= 7.0 * mx);
+        const double c = 0.25 * (double)j;
+        const double t = fma(-c, mx, mn) / fma(c, mn, mx);
+        r = ATAN_C[j] + atan_small(t);
     }
     if (ay > ax)
         r = 1.57079632679489662 - r;

@@ -1235,19 +1235,10 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const T *__restrict__ s
 // in double with a fixed sequence of IEEE operations and rounded once to
 // float, so the same source gives the same bits on the host.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double atan_small(double t)
+__device__ __forceinline__ double atan_small(double t) // |t| < 1/8
 {
     const double s = t * t;
-    double q = -1.0 / 35.0;
-    q = fma(q, s, 1.0 / 33.0);
-    q = fma(q, s, -1.0 / 31.0);
-    q = fma(q, s, 1.0 / 29.0);
-    q = fma(q, s, -1.0 / 27.0);
-    q = fma(q, s, 1.0 / 25.0);
-    q = fma(q, s, -1.0 / 23.0);
-    q = fma(q, s, 1.0 / 21.0);
-    q = fma(q, s, -1.0 / 19.0);
-    q = fma(q, s, 1.0 / 17.0);
+    double q = 1.0 / 17.0;
     q = fma(q, s, -1.0 / 15.0);
     q = fma(q, s, 1.0 / 13.0);
     q = fma(q, s, -1.0 / 11.0);
@@ -1258,22 +1249,26 @@ __device__ __forceinline__ double atan_small(double t)
     return fma(t * s, q, t);
 }
 
+// With a = min/max of |x|,|y| and c the nearest of 0, 1/4, 1/2, 3/4, 1:
+// atan(a) = atan(c) + atan(t), t = (a - c)/(1 + a c) = (min - c max)/(max + c min),
+// |t| < 0.1245: one division and a series up to t^17.
 __device__ float det_atan2f(float yf, float xf)
 {
     const double x = (double)xf, y = (double)yf;
     const double ax = fabs(x), ay = fabs(y);
     const double mx = ax > ay ? ax : ay;
     const double mn = ax > ay ? ay : ax;
-    // One polynomial evaluation serves both ranges: the argument and the
-    // constant term are selected first (0 + atan_small(a) is atan_small(a)
-    // exactly), so lanes that fall on different sides of the split do not
-    // make the wave run the series twice.
     double r = 0.0;
     if (mx != 0.0) {
-        const double a = mn / mx;
-        const bool upper = a > 0.41421356237309503;
-        const double t = upper ? (a - 1.0) / (a + 1.0) : a;
-        const double base = upper ? 0.78539816339744831 : 0.0;
+        const double m8 = 8.0 * mn;
+        const int j = (m8 >= mx) + (m8 >= 3.0 * mx) + (m8 >= 5.0 * mx) + (m8 >= 7.0 * mx);
+        const double c = 0.25 * (double)j;
+        const double t = fma(-c, mx, mn) / fma(c, mn, mx);
+        const double base = j == 0 ? 0.0
+                            : j == 1 ? 0.24497866312686414
+                            : j == 2 ? 0.46364760900080609
+                            : j == 3 ? 0.64350110879328437
+                                     : 0.78539816339744831;
         r = base + atan_small(t);
     }
     if (ay > ax) r = 1.57079632679489662 - r;
