@@ -66,6 +66,42 @@ def gen_images(n, seed0, dense, threads):
     return imgs
 
 
+def host_fed_rates(sift_amd, torch, host, d_pts, steps):
+    """Images/s when every step first has to bring its batch over PCIe from pinned host memory.
+    The batch is cut in two halves; the upload of a half runs on a copy stream while the other
+    half is being extracted.  Not the headline: the boundary of the hot path takes device buffers."""
+    res = {}
+    n = host.shape[0]
+    half = n // 2
+    for name, arr in (("u8", host.astype(np.uint8)), ("f32", host)):
+        pinned = torch.from_numpy(arr).pin_memory()
+        dev = [torch.empty_like(pinned[:half], device="cuda"), torch.empty_like(pinned[half:], device="cuda")]
+        parts = [pinned[:half], pinned[half:]]
+        copy = torch.cuda.Stream()
+        done = [torch.cuda.Event(), torch.cuda.Event()]
+        cap = d_pts.shape[0] // n
+
+        def step():
+            with torch.cuda.stream(copy):
+                dev[0].copy_(parts[0], non_blocking=True)
+                done[0].record(copy)
+                dev[1].copy_(parts[1], non_blocking=True)
+                done[1].record(copy)
+            for k in (0, 1):
+                torch.cuda.current_stream().wait_event(done[k])
+                sift_amd.extract_batch(dev[k], W, d_pts=d_pts[k * half * cap:(k * half + dev[k].shape[0]) * cap])
+
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res[name] = {"images_per_s": n * steps / dt, "host_GBps": arr.nbytes * steps / dt / 1e9}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,6 +114,9 @@ def main():
     ap.add_argument("--queue-cap", type=int, default=-1,
                     help="candidate queue entries per image and scale (0 = dense detector only; -1 = library default)")
     ap.add_argument("--u8", action="store_true", help="8-bit images in HBM, converted by the pyramid kernel's fetch")
+    ap.add_argument("--host-fed", action="store_true",
+                    help="also time the batch arriving from pinned host memory over PCIe (8-bit and float), "
+                         "upload of one half overlapped with extraction of the other; reported beside, never as, value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=48)
     args = ap.parse_args()
@@ -237,6 +276,8 @@ def main():
                 out["roofline_single_stream"] = {"kernel": kernel_names[dom], "achieved": a1 / 1e9,
                                                  "frac": a1 / HBM_PEAK, "avg_launch_ms": ms1 / max(n1, 1)}
             sift_amd.lib().sift_set_batch_lanes(args.lanes or 2)
+        if world == 1 and args.host_fed:
+            out["host_fed"] = host_fed_rates(sift_amd, torch, host, d_pts, args.steps)
         if world == 1 and not args.no_cpu_baseline:
             import oracle
 
