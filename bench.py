@@ -103,6 +103,7 @@ def host_fed_rates(sift_amd, torch, host, d_pts, steps):
 
 
 def main():
+    global S
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -113,6 +114,7 @@ def main():
     ap.add_argument("--dense", action="store_true", help="high keypoint density images")
     ap.add_argument("--queue-cap", type=int, default=-1,
                     help="candidate queue entries per image and scale (0 = dense detector only; -1 = library default)")
+    ap.add_argument("--scales", type=int, default=S, help="scales per octave (2 = the headline configuration, or 3)")
     ap.add_argument("--u8", action="store_true", help="8-bit images in HBM, converted by the pyramid kernel's fetch")
     ap.add_argument("--host-fed", action="store_true",
                     help="also time the batch arriving from pinned host memory over PCIe (8-bit and float), "
@@ -120,6 +122,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=48)
     args = ap.parse_args()
+    S = args.scales
 
     import torch
     import sift_amd
