@@ -297,7 +297,6 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     // the detector's threshold (cudaSiftD.cu:293), kept per scale in LDS and
     // flushed to the global queue once, after the last row
     __shared__ unsigned lq[S][PQ_CAP];
-    __shared__ unsigned lq_n[S];
     const int lane = threadIdx.x;
     // Workgroups are handed to the 8 XCDs round-robin, each XCD with its own
     // L2.  The remap gives every XCD one contiguous run of (column, strip,
@@ -345,7 +344,11 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     // "lowe" profile has no tiles)
     const bool pre_lane = xq > 8 && xq < w - 8 && (plain || xq_tile != 1);
     const bool pre_lane0 = pre_lane && xq_tile == 0; // rows with y mod 32 = 30: see alias_prefilter_kernel
-    if (lane < S) lq_n[lane] = 0;
+    // the block is one wave: the fill of each list is a wave-uniform register, no
+    // LDS atomic is needed to reserve slots
+    unsigned lq_n[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) lq_n[i] = 0;
     // A queue that has already overflowed is lost (the dense detector will redo its
     // group): strips that start later stop feeding it.
     float thr[S];
@@ -484,12 +487,10 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
                 for (int i = 0; i < S; ++i) {
                     const unsigned long long hits = __ballot(fabsf(__fsub_rn(b[i + 1], b[i + 2])) > thr[i]) & lanes;
                     if (hits) {
-                        unsigned base = 0;
-                        if (lane == 0) base = atomicAdd(&lq_n[i], (unsigned)__popcll(hits));
-                        base = __shfl(base, 0);
-                        const unsigned slot = base + __popcll(hits & ((1ull << lane) - 1ull));
+                        const unsigned slot = lq_n[i] + __popcll(hits & ((1ull << lane) - 1ull));
                         if (((hits >> lane) & 1ull) && slot < PQ_CAP)
                             lq[i][slot] = (unsigned)xq | ((unsigned)yo << 16);
+                        lq_n[i] += (unsigned)__popcll(hits);
                     }
                 }
             }
@@ -514,7 +515,8 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
             if (base + n > (unsigned)qcap) thr[i] = __builtin_inff();
         }
         __syncthreads();
-        if (lane < S) lq_n[lane] = 0;
+#pragma unroll
+        for (int i = 0; i < S; ++i) lq_n[i] = 0;
     };
     // a row adds at most 64 entries per scale, a chunk of 20 rows rarely more
     // than a few: the lists are emptied between chunks once half full
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
         unsigned fill = 0;
 #pragma unroll
         for (int i = 0; i < S; ++i) fill = max(fill, lq_n[i]);
-        if (__builtin_amdgcn_readfirstlane(fill) > PQ_CAP / 2) flush();
+        if (fill > PQ_CAP / 2) flush();
     };
     // prologue: the first FZ_PF rows
 #pragma unroll
