@@ -434,3 +434,33 @@ def test_parameter_validation(sift):
     d = torch.zeros((2, 40, 48), dtype=torch.float64, device="cuda")
     with pytest.raises(sift.SiftError):
         sift.extract_batch(d, 48)
+
+
+def test_command_line_front_end(sift, oracle_mod, tmp_path):
+    """sift_cli <list file> <destination> (the counterpart of Sift/src/main.cc): run as a
+    separate process, its text files equal the oracle's."""
+    import subprocess
+    from pnm import write_pnm
+
+    exe = os.path.join(os.path.dirname(os.path.abspath(sift.__file__)), "sift_cli")
+    assert os.path.exists(exe), "make -C sift_amd/csrc builds it"
+    src, dst = tmp_path / "in", tmp_path / "out"
+    src.mkdir()
+    dst.mkdir()
+    imgs = []
+    for i in range(3):
+        img = sift.synth_image(200 + 30 * i, 150, seed=810 + i, dense=True)
+        write_pnm(str(src / f"im{i}.pgm"), img.astype(np.uint8))
+        imgs.append(img)
+    lst = tmp_path / "list.txt"
+    lst.write_text("".join(f"{src / f'im{i}.pgm'}\n" for i in range(3)))
+    r = subprocess.run([exe, str(lst), str(dst), "--octaves", "3", "--cap", "4000"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    pr = oracle_mod.params(n_scales=2, n_octaves=3, max_points=4000)
+    for i, img in enumerate(imgs):
+        ref, _, total = oracle_mod.extract(pr, img, img.shape[1])
+        assert total == len(ref) > 10
+        got = open(dst / f"im{i}.pgm.sift.txt").read().splitlines()
+        assert sorted(got) == sorted(oracle_mod.format_points(ref).splitlines())
+    r = subprocess.run([exe, str(tmp_path / "missing.txt"), str(dst)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "Unable to open file" in r.stderr

@@ -16,6 +16,26 @@ __global__ __launch_bounds__(64) void strips(float *out, const float *in, int p,
     const float *s = in + blockIdx.z * (long)p * h;
     const long plane = (long)p * h;
     float v = (float)lane;
+    if (NT & 16) { // two planes per store instruction: lanes 0..31 write plane 2j, lanes 32..63 plane 2j+1, 8 bytes each
+        float g[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = s[(long)min(y0 + q, h - 1) * p + x];
+        const int half = lane >> 5, xc = blockIdx.x * 64 + 2 * (lane & 31);
+        for (int y = y0; y < y1; y += 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v += g[q];
+                g[q] = s[(long)min(y + q + 4, h - 1) * p + x];
+                if (y + q < y1) {
+#pragma unroll
+                    for (int i = 0; i + 1 < NPL; i += 2)
+                        *reinterpret_cast<float2 *>(&o[(i + half) * plane + (long)(y + q) * p + xc]) = float2{v + i, v - i};
+                    if (NPL & 1) o[(NPL - 1) * plane + (long)(y + q) * p + x] = v;
+                }
+            }
+        }
+        return;
+    }
     if (NT & 4) { // source rows fetched four rows ahead, as the pyramid kernel does
         float g[4];
 #pragma unroll
@@ -75,7 +95,7 @@ int main()
                 case 0: hipLaunchKernelGGL((strips<NPL, false, 0>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride); break;
                 case 1: hipLaunchKernelGGL((strips<NPL, true, 0>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride); break;
                 case 2: hipLaunchKernelGGL((strips<NPL, false, 1>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride); break;
-                case 3: hipLaunchKernelGGL((strips<NPL, true, 1>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride); break;
+                case 3: hipLaunchKernelGGL((strips<5, true, 16>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride); break;
                 case 4: hipLaunchKernelGGL((strips<5, true, 4>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride); break;
                 case 5: hipLaunchKernelGGL((strips<NPL, true, 4>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride); break;
                 case 6: hipLaunchKernelGGL((strips<5, true, 0>), grid, dim3(64), 0, 0, out, in, p, h, rows, img_stride); break;
@@ -87,8 +107,8 @@ int main()
                 hipEventElapsedTime(&ms, e0, e1);
                 if (it && ms < best) best = ms;
             }
-            static const char *nm[] = {"6pl store", "6pl store+load", "6pl nt-store", "6pl nt-store+load", "5pl store+prefetched load", "6pl store+prefetched load", "5pl store+load", "5pl prefetched, rows interleaved"};
-            const double by = bytes * ((rd == 6 || rd == 4 || rd == 7) ? 5.0 / 6 : 1.0);
+            static const char *nm[] = {"6pl store", "6pl store+load", "6pl nt-store", "5pl prefetched, paired-plane 8B stores", "5pl store+prefetched load", "6pl store+prefetched load", "5pl store+load", "5pl prefetched, rows interleaved"};
+            const double by = bytes * ((rd == 6 || rd == 4 || rd == 7 || rd == 3) ? 5.0 / 6 : 1.0);
             printf("%-22s rows=%d: %.3f ms  write %.2f TB/s\n", nm[rd], rows, best, by / best / 1e9);
         }
     }
