@@ -17,6 +17,12 @@ extern "C" {
 #define HL_MAX_PLANES 7 /* n_scales + 3, n_scales <= 4 */
 #define HL_MAX_OCT 8
 #define HL_MAX_GROUPS 32 /* (octave, scale) pairs */
+/* Per-image counter block, HL_COUNT_WORDS words in three cache lines: accepted
+ * points per group, queued candidates per group, and at HL_FULL_WORD the
+ * announcement HL_MAX_GROUPS - g of the first group g that reached the cap
+ * (0 = none), kept away from the counters the atomics hammer. */
+#define HL_FULL_WORD (2 * HL_MAX_GROUPS)
+#define HL_COUNT_WORDS (3 * HL_MAX_GROUPS)
 
 /* blur taps folded by symmetry and interleaved by plane:
  * t[m][i] = c[i*19 + m], m = 0..9, i = plane (padded to 8) */

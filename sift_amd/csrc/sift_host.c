@@ -22,7 +22,7 @@
 #define N_LANES 2
 #define QUEUE_CAP 65536 /* first-octave contrast candidates per image and scale before the dense fall-back */
 #define QUEUE_MIN 4096
-#define COUNT_WORDS (2 * HL_MAX_GROUPS)
+#define COUNT_WORDS HL_COUNT_WORDS
 
 /* ---- state ---------------------------------------------------------------- */
 typedef struct {
@@ -39,7 +39,7 @@ typedef struct {
     long queue_off[SIFT_MAX_OCTAVES]; /* words, inside one image's queue block */
     int qcap[SIFT_MAX_OCTAVES];
     long queue_stride;                /* words per image */
-    unsigned *counts; /* nimg * 2 * HL_MAX_GROUPS: accepted per group, then queued per group */
+    unsigned *counts; /* nimg * HL_COUNT_WORDS: accepted per group, queued per group, the full-group word */
     unsigned *cand;   /* nimg * groups * cap */
     long cand_stride;
     unsigned *queue;  /* nimg * queue_stride: contrast candidates per octave and scale */

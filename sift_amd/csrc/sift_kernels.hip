@@ -882,8 +882,10 @@ __device__ __forceinline__ bool edge_ok(const float *__restrict__ b, int p, floa
     return (trace * trace) / det < edge_limit;
 }
 
+constexpr int DET_THREADS = 512; // threads of a dense-detector block (a multiple of 32 dividing 1024)
+
 template <int S>
-__global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ arena, long arena_stride,
+__global__ __launch_bounds__(DET_THREADS) void detect_kernel(const float *__restrict__ arena, long arena_stride,
                                                      unsigned *cand, long cand_stride,
                                                      unsigned *counts, long counts_stride,
                                                      const unsigned *gate, long gate_stride,
@@ -897,14 +899,32 @@ __global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ a
     const int z = blockIdx.z;
     cand += z * cand_stride;
     counts += z * counts_stride;
+    unsigned *full = counts + HL_FULL_WORD;
+    // the groups to work on, as a bit mask read once (block-uniform)
+    unsigned todo = 0xffffffffu;
     if (gate) { // nothing to do for this image unless one of its queues overflowed
         gate += z * gate_stride;
-        bool any = false;
-        for (int g = 0; g < a.n_oct * S; ++g) any = any || gate[g] > (unsigned)a.oct[g / S].qcap;
-        if (!any) return; // block-uniform
+        todo = 0;
+        for (int g = 0; g < a.n_oct * S; ++g)
+            if (gate[g] > (unsigned)a.oct[g / S].qcap) todo |= 1u << g;
+        if (!todo) return;
     }
     constexpr int CELLS = XT_WRITTEN * 34;          // cells of a tile that are written
-    constexpr int ROUNDS = (CELLS + 255) / 256;     // per thread
+    constexpr int ROUNDS = (CELLS + DET_THREADS - 1) / DET_THREADS; // per thread
+    // the tile cells of this thread do not depend on the block being worked on:
+    // coordinates, LDS address and whether the next tile overwrites the cell
+    int cell_sx[ROUNDS], cell_sy[ROUNDS];
+    unsigned own = 0, taken = 0; // bit it: the cell exists / is overwritten by the next tile
+#pragma unroll
+    for (int it = 0; it < ROUNDS; ++it) {
+        const int c = threadIdx.x + DET_THREADS * it;
+        const int cc = min(c, CELLS - 1);
+        cell_sy[it] = cc / XT_WRITTEN;
+        cell_sx[it] = cc - cell_sy[it] * XT_WRITTEN;
+        const int j = cell_sx[it] + XT_SDIMX * cell_sy[it] - XT_PLANE_OFF; // the address seen from the next tile
+        if (c < CELLS) own |= 1u << it;
+        if (j >= 0 && (j % XT_SDIMX) < XT_WRITTEN) taken |= 1u << it;
+    }
     // dense0[] counts blocks of 96 x 32 pixels, octave after octave, row-major
     for (int unit = blockIdx.x; unit < a.dense0[a.n_oct]; unit += gridDim.x) {
         const int oi = find_octave(a.dense0, a.n_oct, unit);
@@ -915,54 +935,87 @@ __global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ a
         const int bx = u % xblocks, by = u / xblocks;
         const long plane = (long)p * h;
         const float *blur = arena + z * arena_stride + oc.blur_off;
-#pragma unroll 1
-        for (int i = 0; i < S; ++i) {
-            const int g = oi * S + i;
-            if (gate && gate[g] <= (unsigned)oc.qcap) continue; // block-uniform
-            const float *b3 = blur + i * plane; // blur planes i..i+3: DoG planes i..i+2
-            // every cell's four blur values are requested before the first is used:
-            // one memory round trip for the three tiles
-            float v[ROUNDS][4];
+        if (!((todo >> (oi * S)) & ((1u << S) - 1u))) continue; // block-uniform
+        // The output keeps groups in order up to `cap` points and drops what follows
+        // (cudaSiftH.cu:12-13, 82).  A block that sees a group reach the cap announces
+        // it in a word of its own cache line; from then on that group and all later
+        // ones cannot change the output.  The word is read past the vector L1 together
+        // with the plane loads below.
+        const unsigned announced = __hip_atomic_load(full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // Every cell's S+3 blur values are requested before the first is used: one
+        // memory round trip serves the tiles of all scales of the octave (the scales
+        // share all but two of their planes).
+        float v[ROUNDS][S + 3];
+        const int xb = XT_DATAX * bx - 1, yb = XT_BDIM * by - 1; // image position of tile cell (0, 0)
+        // a block whose tile lies inside the image needs no bounds tests (block-uniform)
+        const bool interior = xb >= 0 && xb + XT_WRITTEN <= w && yb >= 0 && yb + 34 <= h;
+        unsigned inside = 0xffffffffu; // bit it: the cell is a pixel of the image
+        if (!interior) {
+            inside = 0;
 #pragma unroll
             for (int it = 0; it < ROUNDS; ++it) {
-                const int c = min((int)threadIdx.x + 256 * it, CELLS - 1);
-                const int sy = c / XT_WRITTEN, sx = c - sy * XT_WRITTEN;
-                const int x = XT_DATAX * bx - 1 + sx, y = XT_BDIM * by - 1 + sy;
-                const bool in = x >= 0 && x < w && y >= 0 && y < h;
-                const float *q = b3 + (in ? x + (long)p * y : 0);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[it][k] = q[k * plane];
+                const int x = xb + cell_sx[it], y = yb + cell_sy[it];
+                if (x >= 0 && x < w && y >= 0 && y < h) inside |= 1u << it;
             }
+        }
+        const float *corner = blur + xb + (long)p * yb;
+#pragma unroll
+        for (int it = 0; it < ROUNDS; ++it) {
+            const float *q = ((inside >> it) & 1u) ? corner + cell_sx[it] + p * cell_sy[it] : blur;
+#pragma unroll
+            for (int k = 0; k < S + 3; ++k) v[it][k] = q[k * plane];
+        }
+        // first group that is full, if any (every thread read the same word: block-uniform)
+        const int full_from = announced ? HL_MAX_GROUPS - (int)announced : HL_MAX_GROUPS;
+        if (oi * S >= full_from) return; // this octave and all later ones are beyond the cap
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const int g = oi * S + i;
+            if (!((todo >> g) & 1u) || g >= full_from) continue; // block-uniform
+            const float *b3 = blur + i * plane; // blur planes i..i+3: DoG planes i..i+2
             __syncthreads(); // readers of the previous tiles are done
             if (threadIdx.x == 0) hot_n = 0;
-            for (int t = 0; t < 3; ++t) {
+            // The reference writes tile 0, then 1, then 2, and a later tile overwrites the
+            // tail of the one before.  Which write a cell keeps is known from its address:
+            // a cell of tile t survives unless tile t+1 writes the same address, so the
+            // three tiles go out together and only the surviving writes are made.
 #pragma unroll
-                for (int it = 0; it < ROUNDS; ++it) {
-                    const int c = threadIdx.x + 256 * it;
-                    const int sy = c / XT_WRITTEN, sx = c - sy * XT_WRITTEN;
-                    const int x = XT_DATAX * bx - 1 + sx, y = XT_BDIM * by - 1 + sy;
-                    const bool in = x >= 0 && x < w && y >= 0 && y < h;
-                    if (c < CELLS) sh[t * XT_PLANE_OFF + sx + XT_SDIMX * sy] = in ? __fsub_rn(v[it][t], v[it][t + 1]) : 0.f;
+            for (int it = 0; it < ROUNDS; ++it) {
+                const int lin = cell_sx[it] + XT_SDIMX * cell_sy[it];
+                const bool in = (inside >> it) & 1u;
+                if ((own >> it) & 1u) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+                        if (t == 2 || !((taken >> it) & 1u))
+                            sh[t * XT_PLANE_OFF + lin] = in ? __fsub_rn(v[it][i + t], v[it][i + t + 1]) : 0.f;
                 }
-                __syncthreads(); // the next tile overwrites the tail of this one
             }
+            __syncthreads();
             // contrast test first: the survivors are listed, then shared out over the block
             const int tx = threadIdx.x & 31;
 #pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                const int ty = pass * 8 + (threadIdx.x >> 5);
+            for (int pass = 0; pass < XT_BDIM * XT_BDIM / DET_THREADS; ++pass) {
+                const int ty = pass * (DET_THREADS / XT_BDIM) + (threadIdx.x >> 5);
                 const int y = XT_BDIM * by + ty;
 #pragma unroll
                 for (int tile = 0; tile < 3; tile += 2) {
                     const int x = XT_DATAX * bx + tx + XT_BDIM * tile;
                     const float pv = sh[XT_PLANE_OFF + 1 + tx + XT_BDIM * tile + XT_SDIMX * (1 + ty)];
-                    if (x > 8 && x < w - 8 && y > 8 && y < h - 8 && fabsf(pv) > a.contrast)
-                        hot[atomicAdd(&hot_n, 1u)] = (unsigned)tx | ((unsigned)ty << 8) | ((unsigned)tile << 16);
+                    const bool pass = x > 8 && x < w - 8 && y > 8 && y < h - 8 && fabsf(pv) > a.contrast;
+                    const unsigned long long pm = __ballot(pass); // one LDS atomic per wave, not per pixel
+                    if (pm) {
+                        unsigned base = 0;
+                        if (lane == 0) base = atomicAdd(&hot_n, (unsigned)__popcll(pm));
+                        base = __shfl(base, 0);
+                        if (pass)
+                            hot[base + __popcll(pm & ((1ull << lane) - 1ull))] =
+                                (unsigned)tx | ((unsigned)ty << 8) | ((unsigned)tile << 16);
+                    }
                 }
             }
             __syncthreads();
             const unsigned n_hot = hot_n;
-            for (unsigned e0 = 0; e0 < n_hot; e0 += 256) { // block-uniform trip count
+            for (unsigned e0 = 0; e0 < n_hot; e0 += DET_THREADS) { // block-uniform trip count
                 const unsigned e = e0 + threadIdx.x;
                 bool hit = false;
                 unsigned xy = 0;
@@ -986,7 +1039,21 @@ __global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ a
                     xy = (unsigned)x | ((unsigned)y << 16);
                     hit = r == 9 && edge_ok(b3 + plane + x + (long)p * y, p, a.edge_limit);
                 }
-                append_hits(hit, xy, lane, &counts[g], cand + (long)g * a.cap, a.cap);
+                // append, and announce the group once it holds `cap` points
+                const unsigned long long hm = __ballot(hit);
+                if (hm) {
+                    const int leader = __ffsll((long long)hm) - 1;
+                    const unsigned n_new = (unsigned)__popcll(hm);
+                    unsigned base = 0;
+                    if (lane == leader) {
+                        base = atomicAdd(&counts[g], n_new);
+                        if (base < (unsigned)a.cap && base + n_new >= (unsigned)a.cap)
+                            atomicMax(full, (unsigned)(HL_MAX_GROUPS - g));
+                    }
+                    base = __shfl(base, leader);
+                    const unsigned idx = base + __popcll(hm & ((1ull << lane) - 1ull));
+                    if (hit && idx < (unsigned)a.cap) cand[(long)g * a.cap + idx] = xy;
+                }
             }
         }
     }
@@ -1920,13 +1987,13 @@ int hl_detect(const float *arena, long arena_stride, unsigned *cand, long cand_s
     if (!detect_args_ok(a, nimg) || (arena_stride & 3) || (((size_t)arena) & 15)) return -1001;
     // with a gate the kernel normally has nothing to do: few blocks per image, each
     // walking over the units; without one it is the whole detector and fills the chip
+    // (a block walks over several pixel blocks also because one that has seen a group
+    // reach the cap can drop the rest of its work)
     int gx = a->dense0[a->n_oct] < 4096 ? a->dense0[a->n_oct] : 4096;
-    if (gate) {
-        int per_image = 8192 / nimg;
-        per_image = per_image < 32 ? 32 : (per_image > 1024 ? 1024 : per_image);
-        if (gx > per_image) gx = per_image;
-    }
-    dim3 grid(gx, 1, nimg), block(256);
+    int per_image = (gate ? 8192 : 16384) / nimg;
+    per_image = per_image < 32 ? 32 : (per_image > 1024 ? 1024 : per_image);
+    if (gx > per_image) gx = per_image;
+    dim3 grid(gx, 1, nimg), block(DET_THREADS);
     hipStream_t s = (hipStream_t)stream;
     ScopedTimer t(2, s);
     if (a->n_scales == 2)
