@@ -123,19 +123,26 @@ def test_counts_accumulate_until_reset_and_slots_are_independent(sift, oracle_mo
     assert sift.getPointCount(0) == 0 and sift.getPointCount(1) == 0
 
 
-def test_cap_overflow_keeps_a_subset_and_clamps_the_count(sift, oracle_mod):
+@pytest.mark.parametrize("queue_cap,cap", [(65536, 256), (0, 256), (16, 256), (0, 40), (16, 300)])
+def test_cap_overflow_keeps_a_subset_and_clamps_the_count(sift, oracle_mod, queue_cap, cap):
+    """More keypoints than max_points, through the queue path and through the dense detector
+    (which stops working on an image once a group has reached the cap)."""
     w, h = 640, 480
     img = sift.synth_image(w, h, seed=6, dense=True)
     full, _, _ = oracle_mod.extract(oracle_mod.params(max_points=20000), img, w)
     assert len(full) >= 300
-    sift.set_params(max_points=256)
-    got = _extract_gpu(sift, img, w)
-    assert len(got) == 256
+    sift.set_params(max_points=cap)
+    sift.lib().sift_set_queue_cap(queue_cap)
+    try:
+        got = _extract_gpu(sift, img, w)
+    finally:
+        sift.lib().sift_set_queue_cap(65536)
+    assert len(got) == min(cap, len(full))
     want = {p.tobytes() for p in full}
     assert all(p.tobytes() in want for p in got), "every kept point is a full-run point, bit for bit"
     # whole groups in front of the overflowing one are complete (the reference skips later scales)
     first = full["scale"] == full["scale"][0]
-    if first.sum() < 256:
+    if first.sum() < cap:
         assert (got["scale"] == full["scale"][0]).sum() == first.sum()
 
 
