@@ -1405,7 +1405,10 @@ __global__ __launch_bounds__(64) void keypoint_kernel(
 {
     __shared__ float s_mag[REG * REG + 3];
     __shared__ float s_dir[REG * REG + 3];
-    __shared__ __attribute__((aligned(16))) float s_part[64 * 36];
+    // partial sums: 32 lanes x 32 orientation bins (the two lane halves take turns),
+    // later 64 lanes x 8 descriptor bins.  Kept small: the kernel runs as many waves as
+    // its LDS allows, and it needs them to hide its memory round trips.
+    __shared__ __attribute__((aligned(16))) float s_part[64 * 20];
 
     const int lane = threadIdx.x;
     const int z = blockIdx.y;
@@ -1486,9 +1489,8 @@ __global__ __launch_bounds__(64) void keypoint_kernel(
 
         // ---- orientation: 16x16 patch [x-7,x+8] x [y-7,y+8], 32 bins ----
         const int ty = lane >> 2, tx0 = 4 * (lane & 3);
+        float hsum;
         {
-#pragma unroll
-            for (int q = 0; q < 9; ++q) reinterpret_cast<float4 *>(s_part)[lane + 64 * q] = float4{0.f, 0.f, 0.f, 0.f};
             int ob[4];
             float ow[4], oo[4];
             const float wy = a.wnd[si * 16 + ty];
@@ -1499,25 +1501,36 @@ __global__ __launch_bounds__(64) void keypoint_kernel(
                 ob[k] = assign_bin(s_dir[e], 11.25f);
             }
             chain4(ob, ow, oo);
-            __syncthreads(); // the zeroes are in place
+            // lanes 0..31 leave their partials and every lane adds up its bin's column,
+            // then the same for lanes 32..63: bin = (first half) + (second half)
+            float hh[2];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) s_part[lane * OH_STRIDE + ob[k]] = oo[k]; // in order: the last write of a bin wins
-        }
-        __syncthreads();
-        float hsum = 0.f;
-        {
-            const float *col = s_part + (lane >> 5) * 32 * OH_STRIDE + (lane & 31);
+            for (int half = 0; half < 2; ++half) {
 #pragma unroll
-            for (int i = 0; i < 32; ++i) hsum = __fadd_rn(hsum, col[i * OH_STRIDE]);
+                for (int q = 0; q < 5; ++q) reinterpret_cast<float4 *>(s_part)[lane + 64 * q] = float4{0.f, 0.f, 0.f, 0.f};
+                __syncthreads(); // the zeroes are in place
+                if ((lane >> 5) == half) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        s_part[(lane & 31) * OH_STRIDE + ob[k]] = oo[k]; // in order: the last write of a bin wins
+                }
+                __syncthreads();
+                const float *col = s_part + (lane & 31);
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) acc = __fadd_rn(acc, col[i * OH_STRIDE]);
+                hh[half] = acc;
+                __syncthreads(); // the column sums are taken before the next zeroing
+            }
+            hsum = __fadd_rn(hh[0], hh[1]);
         }
-        hsum = __fadd_rn(hsum, __shfl_down(hsum, 32));
         float mx = hsum;
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 8));
         mx = fmaxf(mx, __shfl_xor(mx, 4));
         mx = fmaxf(mx, __shfl_xor(mx, 2));
         mx = fmaxf(mx, __shfl_xor(mx, 1));
-        const unsigned long long mm = __ballot(lane < 32 && hsum == mx);
+        const unsigned long long mm = __ballot(lane < 32 && hsum == mx); // (lanes 32..63 hold the same 32 bins again)
         const int oidx = mm ? (__ffsll((long long)mm) - 1) : 0; // first maximum wins
         const float orientation = 11.25f * (float)oidx;
         __syncthreads();
