@@ -123,15 +123,16 @@ def test_counts_accumulate_until_reset_and_slots_are_independent(sift, oracle_mo
     assert sift.getPointCount(0) == 0 and sift.getPointCount(1) == 0
 
 
-@pytest.mark.parametrize("queue_cap,cap", [(65536, 256), (0, 256), (16, 256), (0, 40), (16, 300)])
-def test_cap_overflow_keeps_a_subset_and_clamps_the_count(sift, oracle_mod, queue_cap, cap):
+@pytest.mark.parametrize("queue_cap,cap,S", [(65536, 256, 2), (0, 256, 2), (16, 256, 2), (0, 40, 2), (16, 300, 2),
+                                             (0, 100, 3), (16, 350, 3)])
+def test_cap_overflow_keeps_a_subset_and_clamps_the_count(sift, oracle_mod, queue_cap, cap, S):
     """More keypoints than max_points, through the queue path and through the dense detector
     (which stops working on an image once a group has reached the cap)."""
     w, h = 640, 480
     img = sift.synth_image(w, h, seed=6, dense=True)
-    full, _, _ = oracle_mod.extract(oracle_mod.params(max_points=20000), img, w)
+    full, _, _ = oracle_mod.extract(oracle_mod.params(max_points=20000, n_scales=S), img, w)
     assert len(full) >= 300
-    sift.set_params(max_points=cap)
+    sift.set_params(max_points=cap, n_scales=S)
     sift.lib().sift_set_queue_cap(queue_cap)
     try:
         got = _extract_gpu(sift, img, w)
