@@ -1320,30 +1320,42 @@ __device__ __forceinline__ double atan_small(double t) // |t| < 1/8
 
 // With a = min/max of |x|,|y| and c the nearest of 0, 1/4, 1/2, 3/4, 1:
 // atan(a) = atan(c) + atan(t), t = (a - c)/(1 + a c) = (min - c max)/(max + c min),
-// |t| < 0.1245: one division and a series up to t^17.
-__device__ float det_atan2f(float yf, float xf)
+// |t| < 0.1245: one division and a series up to t^17.  `tab(j, c, base)` supplies
+// c = j/4 and atan(c).  Evaluated without a branch: for x = y = 0 the quotient is
+// 0/0 and the result is replaced by 0 afterwards.
+template <class Tab>
+__device__ __forceinline__ float det_atan2f_with(float yf, float xf, Tab tab)
 {
     const double x = (double)xf, y = (double)yf;
     const double ax = fabs(x), ay = fabs(y);
     const double mx = ax > ay ? ax : ay;
     const double mn = ax > ay ? ay : ax;
-    double r = 0.0;
-    if (mx != 0.0) {
-        const double m8 = 8.0 * mn;
-        const int j = (m8 >= mx) + (m8 >= 3.0 * mx) + (m8 >= 5.0 * mx) + (m8 >= 7.0 * mx);
-        const double c = 0.25 * (double)j;
-        const double t = fma(-c, mx, mn) / fma(c, mn, mx);
-        const double base = j == 0 ? 0.0
-                            : j == 1 ? 0.24497866312686414
-                            : j == 2 ? 0.46364760900080609
-                            : j == 3 ? 0.64350110879328437
-                                     : 0.78539816339744831;
-        r = base + atan_small(t);
-    }
+    const double m8 = 8.0 * mn;
+    const int j = (m8 >= mx) + (m8 >= 3.0 * mx) + (m8 >= 5.0 * mx) + (m8 >= 7.0 * mx);
+    double c, base;
+    tab(j, c, base);
+    const double t = fma(-c, mx, mn) / fma(c, mn, mx);
+    double r = base + atan_small(t);
+    r = mx != 0.0 ? r : 0.0;
     if (ay > ax) r = 1.57079632679489662 - r;
     if (x < 0.0) r = 3.14159265358979323846 - r;
     if (y < 0.0) r = -r;
     return (float)r;
+}
+
+constexpr double ATAN_QUARTERS[5] = {0.0, 0.24497866312686414, 0.46364760900080609, 0.64350110879328437,
+                                     0.78539816339744831};
+
+__device__ float det_atan2f(float yf, float xf)
+{
+    return det_atan2f_with(yf, xf, [](int j, double &c, double &base) {
+        c = 0.25 * (double)j;
+        base = j == 0 ? ATAN_QUARTERS[0]
+               : j == 1 ? ATAN_QUARTERS[1]
+               : j == 2 ? ATAN_QUARTERS[2]
+               : j == 3 ? ATAN_QUARTERS[3]
+                        : ATAN_QUARTERS[4];
+    });
 }
 
 __device__ __forceinline__ void grad_from(float up, float down, float left, float right, float &mag,
@@ -1362,6 +1374,20 @@ __device__ __forceinline__ void grad_from(float up, float down, float left, floa
     mag = sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy))); // correctly rounded (the _rn intrinsic is the fast approximation)
     dir = (float)((180 / 3.14159265) * (double)det_atan2f(dy, dx)); // PI of utils.h:4
 }
+// the same with c and atan(c) read from a table of five (c, atan c) pairs in LDS
+__device__ __forceinline__ void grad_from(float up, float down, float left, float right, const double2 *tab,
+                                          float &mag, float &dir)
+{
+    const float dx = right - left;
+    const float dy = down - up;
+    mag = sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+    const float rad = det_atan2f_with(dy, dx, [tab](int j, double &c, double &base) {
+        const double2 e = tab[j];
+        c = e.x;
+        base = e.y;
+    });
+    dir = (float)((180 / 3.14159265) * (double)rad);
+}
 
 // cudaAssignBin cudaSiftD.h:35-41; theta is within [-360, 360]
 __device__ __forceinline__ int assign_bin(float theta, float bin_range)
@@ -1377,6 +1403,88 @@ struct SiftPointD {
 };
 
 constexpr int REG = 23; // gradient region [x-11, x+11]: covers the rotated 16x16 patch
+
+// The descriptor's rotated 16x16 samples read, through their bilinear corners,
+// only part of the 23x23 region, and which part depends on the orientation
+// alone.  For each of the 32 orientations: the region entries outside the
+// upright 16x16 patch (entries [4,19] x [4,19], which the orientation histogram
+// needs anyway) that some sample can touch.  A sample's corner is
+// floor(x + u) - x with the sum rounded to float; for x < 2^16 that rounding
+// moves the sum by less than 2^-8, and the float evaluation of u by far less,
+// so the cells of floor(u - 1/64) and floor(u + 1/64) cover every case.
+constexpr int PATCH0 = 4, PATCH1 = 19; // the upright patch inside the region
+constexpr int RING_MAX = 96;
+struct RingTable {
+    unsigned short n[32];
+    unsigned short e[32][RING_MAX];
+};
+constexpr double cx_sin(double x) // |x| <= pi
+{
+    double term = x, sum = x;
+    for (int k = 1; k < 18; ++k) {
+        term *= -x * x / (double)((2 * k) * (2 * k + 1));
+        sum += term;
+    }
+    return sum;
+}
+constexpr double cx_cos(double x)
+{
+    double term = 1.0, sum = 1.0;
+    for (int k = 1; k < 18; ++k) {
+        term *= -x * x / (double)((2 * k - 1) * (2 * k));
+        sum += term;
+    }
+    return sum;
+}
+constexpr int cx_floor(double v)
+{
+    const int i = (int)v;
+    return (double)i > v ? i - 1 : i;
+}
+constexpr int cx_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+constexpr RingTable make_ring_table()
+{
+    RingTable t{};
+    const double pi = 3.14159265358979323846, margin = 1.0 / 64.0;
+    for (int o = 0; o < 32; ++o) {
+        double rad = 11.25 * o * pi / 180.0;
+        if (rad > pi) rad -= 2.0 * pi;
+        const double cs = cx_cos(rad), sn = cx_sin(rad);
+        bool used[REG * REG] = {};
+        for (int ty = 0; ty < 16; ++ty)
+            for (int tx = 0; tx < 16; ++tx) {
+                const double dx = tx - 7.5, dy = ty - 7.5;
+                const double u = dx * cs + dy * sn, v = dy * cs - dx * sn;
+                for (int a = 0; a < 2; ++a)
+                    for (int b = 0; b < 2; ++b) {
+                        const int rx = cx_clamp(cx_floor(u + (a ? margin : -margin)) + 11, 0, REG - 2);
+                        const int ry = cx_clamp(cx_floor(v + (b ? margin : -margin)) + 11, 0, REG - 2);
+                        used[ry * REG + rx] = used[ry * REG + rx + 1] = true;
+                        used[(ry + 1) * REG + rx] = used[(ry + 1) * REG + rx + 1] = true;
+                    }
+            }
+        int n = 0;
+        for (int e = 0; e < REG * REG; ++e) {
+            const int ry = e / REG, rx = e - ry * REG;
+            const bool in_patch = ry >= PATCH0 && ry <= PATCH1 && rx >= PATCH0 && rx <= PATCH1;
+            if (used[e] && !in_patch) {
+                if (n < RING_MAX) t.e[o][n] = (unsigned short)e;
+                ++n;
+            }
+        }
+        t.n[o] = (unsigned short)n;
+    }
+    return t;
+}
+constexpr RingTable RING_HOST = make_ring_table();
+constexpr bool ring_fits()
+{
+    for (int o = 0; o < 32; ++o)
+        if (RING_HOST.n[o] > RING_MAX) return false;
+    return true;
+}
+static_assert(ring_fits(), "RING_MAX is too small for some orientation");
+__device__ const RingTable g_ring = RING_HOST;
 
 // One wave per keypoint.  Float sums whose order the reference leaves to
 // atomics are taken in one fixed order built from per-lane partial sums.  Lane
@@ -1398,6 +1506,92 @@ __device__ __forceinline__ void chain4(const int (&b)[4], const float (&w)[4], f
     o[3] = __fadd_rn(b[3] == b[2] ? o[2] : (b[3] == b[1] ? o[1] : (b[3] == b[0] ? o[0] : 0.f)), w[3]);
 }
 
+__device__ __forceinline__ double ATAN_QUARTERS_DEV(int j)
+{
+    return j == 0 ? ATAN_QUARTERS[0] : j == 1 ? ATAN_QUARTERS[1] : j == 2 ? ATAN_QUARTERS[2]
+           : j == 3 ? ATAN_QUARTERS[3] : ATAN_QUARTERS[4];
+}
+
+// The four neighbours of region entry (rx, ry) of the keypoint at (x, y): the
+// entry stands for pixel clamp(x - 11 + rx), clamp(y - 11 + ry), and a neighbour
+// outside the image counts as 0 (gradientKernel cudaSiftD.cu:336-347).  The loads
+// use clamped addresses; region_values replaces what lay outside.
+template <bool INTERIOR>
+__device__ __forceinline__ void region_loads(const float *bl, int w, int p, int h, int x, int y, int rx,
+                                             int ry, float (&nb)[4])
+{
+    if (INTERIOR) {
+        const float *c = bl + (x - 11 + rx) + (long)p * (y - 11 + ry);
+        nb[0] = c[-p];
+        nb[1] = c[p];
+        nb[2] = c[-1];
+        nb[3] = c[1];
+    } else {
+        const int px = min(max(x - 11 + rx, 0), w - 1);
+        const int py = min(max(y - 11 + ry, 0), h - 1);
+        const float *c = bl + px + (long)p * py;
+        nb[0] = c[py > 0 ? -p : 0];
+        nb[1] = c[py < h - 1 ? p : 0];
+        nb[2] = c[px > 0 ? -1 : 0];
+        nb[3] = c[px < w - 1 ? 1 : 0];
+    }
+}
+template <bool INTERIOR>
+__device__ __forceinline__ void region_values(int w, int h, int x, int y, int rx, int ry, float (&nb)[4])
+{
+    if (!INTERIOR) {
+        const int px = min(max(x - 11 + rx, 0), w - 1);
+        const int py = min(max(y - 11 + ry, 0), h - 1);
+        nb[0] = py > 0 ? nb[0] : 0.f;
+        nb[1] = py < h - 1 ? nb[1] : 0.f;
+        nb[2] = px > 0 ? nb[2] : 0.f;
+        nb[3] = px < w - 1 ? nb[3] : 0.f;
+    }
+}
+
+template <bool INTERIOR>
+__device__ __forceinline__ void region_patch(const float *bl, int w, int p, int h, int x, int y, int lane,
+                                             const double2 *tab, float *s_mag, float *s_dir)
+{
+    float nb[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = lane + 64 * q;
+        region_loads<INTERIOR>(bl, w, p, h, x, y, PATCH0 + (i & 15), PATCH0 + (i >> 4), nb[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = lane + 64 * q;
+        const int rx = PATCH0 + (i & 15), ry = PATCH0 + (i >> 4);
+        region_values<INTERIOR>(w, h, x, y, rx, ry, nb[q]);
+        float m, d;
+        grad_from(nb[q][0], nb[q][1], nb[q][2], nb[q][3], tab, m, d);
+        s_mag[ry * REG + rx] = m;
+        s_dir[ry * REG + rx] = d;
+    }
+}
+
+template <bool INTERIOR>
+__device__ __forceinline__ void region_ring(const float *bl, int w, int p, int h, int x, int y, int lane,
+                                            int oidx, const double2 *tab, float *s_mag, float *s_dir)
+{
+    const int n = g_ring.n[oidx];
+    for (int i0 = 0; i0 < n; i0 += 64) { // one or two turns
+        const int i = i0 + lane;
+        if (i < n) {
+            const int e = g_ring.e[oidx][i];
+            const int ry = e / REG, rx = e - ry * REG;
+            float nb[4];
+            region_loads<INTERIOR>(bl, w, p, h, x, y, rx, ry, nb);
+            region_values<INTERIOR>(w, h, x, y, rx, ry, nb);
+            float m, d;
+            grad_from(nb[0], nb[1], nb[2], nb[3], tab, m, d);
+            s_mag[e] = m;
+            s_dir[e] = d;
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void keypoint_kernel(
     SiftPointD *pts, long pts_stride, unsigned char *meta, const float *arena, long arena_stride,
     const unsigned *cand, const float4 *sub, long cand_stride, const unsigned *counts,
@@ -1409,8 +1603,10 @@ __global__ __launch_bounds__(64) void keypoint_kernel(
     // later 64 lanes x 8 descriptor bins.  Kept small: the kernel runs as many waves as
     // its LDS allows, and it needs them to hide its memory round trips.
     __shared__ __attribute__((aligned(16))) float s_part[64 * 20];
+    __shared__ double2 s_tab[5]; // (j/4, atan(j/4))
 
     const int lane = threadIdx.x;
+    if (lane < 5) s_tab[lane] = double2{0.25 * (double)lane, ATAN_QUARTERS_DEV(lane)};
     const int z = blockIdx.y;
     pts += z * pts_stride;
     if (meta) meta += z * pts_stride * 2;
@@ -1450,41 +1646,18 @@ __global__ __launch_bounds__(64) void keypoint_kernel(
         const float *bl = arena + oc.blur_off + (long)(si + 1) * p * h; // blur plane si+1
 
         __syncthreads(); // previous keypoint's readers are done with the LDS arrays
-        {
-            // all 36 neighbour loads of the lane are issued before the first is used:
-            // one memory round trip per keypoint instead of nine
-            constexpr int ROUNDS = (REG * REG + 63) / 64;
-            float nb[ROUNDS][4];
-#pragma unroll
-            for (int q = 0; q < ROUNDS; ++q) {
-                const int e = min(lane + 64 * q, REG * REG - 1);
-                const int ry = e / REG, rx = e - ry * REG;
-                const int px = min(max(x - 11 + rx, 0), w - 1);
-                const int py = min(max(y - 11 + ry, 0), h - 1);
-                const float *c = bl + px + (long)p * py;
-                // clamped addresses, values outside the image replaced by 0 afterwards
-                nb[q][0] = c[py > 0 ? -p : 0];
-                nb[q][1] = c[py < h - 1 ? p : 0];
-                nb[q][2] = c[px > 0 ? -1 : 0];
-                nb[q][3] = c[px < w - 1 ? 1 : 0];
-            }
-#pragma unroll
-            for (int q = 0; q < ROUNDS; ++q) {
-                const int e = lane + 64 * q;
-                const int ec = min(e, REG * REG - 1);
-                const int ry = ec / REG, rx = ec - ry * REG;
-                const int px = min(max(x - 11 + rx, 0), w - 1);
-                const int py = min(max(y - 11 + ry, 0), h - 1);
-                const float up = py > 0 ? nb[q][0] : 0.f, down = py < h - 1 ? nb[q][1] : 0.f;
-                const float left = px > 0 ? nb[q][2] : 0.f, right = px < w - 1 ? nb[q][3] : 0.f;
-                float m, d;
-                grad_from(up, down, left, right, m, d);
-                if (e < REG * REG) {
-                    s_mag[e] = m;
-                    s_dir[e] = d;
-                }
-            }
-        }
+#ifdef SIFT_POISON_REGION
+        // test builds only: an entry that is read without having been computed for
+        // this keypoint turns the descriptor into NaNs
+        for (int e = lane; e < REG * REG; e += 64) s_mag[e] = s_dir[e] = __builtin_nanf("");
+        __syncthreads();
+#endif
+        // away from the border no address needs clamping and no value replacing
+        const bool interior = x >= 12 && x + 12 <= w - 1 && y >= 12 && y + 12 <= h - 1;
+        // the upright 16x16 patch first: four entries per lane, all 16 neighbour loads
+        // issued before the first is used (one memory round trip)
+        if (interior) region_patch<true>(bl, w, p, h, x, y, lane, s_tab, s_mag, s_dir);
+        else region_patch<false>(bl, w, p, h, x, y, lane, s_tab, s_mag, s_dir);
         __syncthreads();
 
         // ---- orientation: 16x16 patch [x-7,x+8] x [y-7,y+8], 32 bins ----
@@ -1533,6 +1706,9 @@ __global__ __launch_bounds__(64) void keypoint_kernel(
         const unsigned long long mm = __ballot(lane < 32 && hsum == mx); // (lanes 32..63 hold the same 32 bins again)
         const int oidx = mm ? (__ffsll((long long)mm) - 1) : 0; // first maximum wins
         const float orientation = 11.25f * (float)oidx;
+        // the entries around the patch that this orientation's descriptor samples touch
+        if (interior) region_ring<true>(bl, w, p, h, x, y, lane, oidx, s_tab, s_mag, s_dir);
+        else region_ring<false>(bl, w, p, h, x, y, lane, oidx, s_tab, s_mag, s_dir);
         __syncthreads();
 
         // ---- descriptor: rotated 16x16 samples, bilinear, 4x4 cells x 8 bins ----
