@@ -352,6 +352,30 @@ def test_large_8k_image_against_oracle(sift, oracle_mod):
     sift.shutdown()  # give the 1.2 GB of arena and lists back before the next test
 
 
+@pytest.mark.parametrize("profile", [1, 0])
+def test_upsampled_8k_image_against_oracle(sift, oracle_mod, profile):
+    """The largest configuration, 15360x8640 with 177 Mpx of pyramid and cap 2^20: a dense
+    7680x4320 image doubled by the library (profile "lowe", 6 + 1 octaves), and the doubled image
+    handed in as it is (profile "ref", 6 octaves)."""
+    w, h = 7680, 4320
+    img = sift.synth_image(w, h, seed=9001, dense=True)
+    if profile == 1:
+        kw = dict(n_scales=2, n_octaves=6, max_points=1 << 20, profile=1, upsample=1)
+    else:
+        kw = dict(n_scales=2, n_octaves=6, max_points=1 << 20)
+        img = np.rint(oracle_mod.upsample2x(img, w))  # integers, like a decoded image
+        w, h = 2 * w, 2 * h
+    pr = _params(sift, oracle_mod, **kw)
+    ref, meta, total = oracle_mod.extract(pr, img, w)
+    assert total == len(ref) > 20000
+    try:
+        got = _extract_gpu(sift, img, w)
+    finally:
+        sift.set_params()
+    _assert_points_equal(oracle_mod, got, ref)
+    sift.shutdown()
+
+
 @pytest.mark.parametrize(
     "w,h,S,O,seed,up,qcap",
     [(640, 480, 2, 4, 1, 0, 65536), (333, 250, 3, 3, 2, 0, 65536), (400, 300, 2, 3, 3, 1, 65536),
