@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--host-fed", action="store_true",
                     help="also time the batch arriving from pinned host memory over PCIe (8-bit and float), "
                          "upload of one half overlapped with extraction of the other; reported beside, never as, value")
+    ap.add_argument("--profile", choices=["ref", "lowe"], default="ref",
+                    help="semantics profile (ref = the headline configuration)")
+    ap.add_argument("--upsample", action="store_true", help="profile lowe: doubled first octave")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=48)
     args = ap.parse_args()
@@ -154,7 +157,8 @@ def main():
             os.close(saved)
 
     sift_amd.lib()  # raises if the HIP library is missing
-    sift_amd.set_params(n_octaves=O, n_scales=S, max_points=CAP)
+    profile = 1 if args.profile == "lowe" else 0
+    sift_amd.set_params(n_octaves=O, n_scales=S, max_points=CAP, profile=profile, upsample=int(args.upsample))
     if args.chunk:
         sift_amd.lib().sift_set_batch_chunk(args.chunk)
     if args.lanes:
@@ -214,7 +218,8 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"{args.batch} synthetic {W}x{H} {'u8' if args.u8 else 'f32'} images per GPU, {S} scales, {O} octaves, "
-                        f"cap {CAP}, semantics profile ref, inputs resident in HBM"
+                        f"cap {CAP}, semantics profile {args.profile}{' with doubled first octave' if args.upsample else ''}, "
+                        f"inputs resident in HBM"
                         + (", dense blobs" if args.dense else ""),
             "parallelism": f"dp{world} (independent image batches, no collective)",
         },
@@ -224,7 +229,7 @@ def main():
 
     if rank == 0:
         ab = algorithmic_bytes(S)
-        px = sum(octave_pixels(W, H, O))
+        px = sum(octave_pixels(2 * W, 2 * H, O + 1)) if args.upsample else sum(octave_pixels(W, H, O))
         names = {"pyramid": sift_amd.K_PYRAMID, "alias": sift_amd.K_ALIAS, "verify": sift_amd.K_VERIFY,
                  "detect": sift_amd.K_DETECT, "keypoint": sift_amd.K_KEYPOINT}
         kern = {}
@@ -284,7 +289,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             import oracle
 
-            pr = oracle.params(n_octaves=O, n_scales=S, max_points=CAP)
+            pr = oracle.params(n_octaves=O, n_scales=S, max_points=CAP, profile=profile, upsample=int(args.upsample))
             n_cpu = min(args.cpu_sample, args.batch)
             t0 = time.perf_counter()
             _, cpu_counts = oracle.extract_batch(pr, host[:n_cpu], W, n_threads=threads)

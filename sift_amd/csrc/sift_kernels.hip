@@ -284,19 +284,21 @@ constexpr int XT_SDIMX = 101;
 constexpr int XT_WRITTEN = 98;
 constexpr int XT_PLANE_OFF = 3168;
 
-template <int S, int SRC_MODE>
+template <int S, int SRC_MODE, bool PLAIN>
 __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     const float *__restrict__ src, int src_w, int src_h, int src_pitch, long src_stride,
     float *__restrict__ blur, long blur_stride, int w, int p, int h, int rows, hl_taps taps, float contrast, unsigned *__restrict__ queue,
-    long queue_stride, unsigned *__restrict__ qcount, long qcount_stride, int qcap, int group0,
-    int plain)
+    long queue_stride, unsigned *__restrict__ qcount, long qcount_stride, int qcap, int group0)
 {
     constexpr int NP = S + 3;
+    constexpr bool plain = PLAIN; // the detector without tiles ("lowe" profile)
     __shared__ float lds[2][128];
     // contrast candidates of this strip: pixels whose centre-plane DoG exceeds
     // the detector's threshold (cudaSiftD.cu:293), kept per scale in LDS and
     // flushed to the global queue once, after the last row
     __shared__ unsigned lq[S][PQ_CAP];
+    // plain detector only: the centre DoG values of the previous output row
+    __shared__ float d_up[PLAIN ? S : 1][64];
     const int lane = threadIdx.x;
     // Workgroups are handed to the 8 XCDs round-robin, each XCD with its own
     // L2.  The remap gives every XCD one contiguous run of (column, strip,
@@ -417,6 +419,16 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     // lanes the detector pre-filter may queue, as wave masks
     const unsigned long long pre_mask = __ballot(pre_lane), pre_mask0 = __ballot(pre_lane0);
 
+    // appends the lanes of `hits` to the wave's list of scale i as pixels of row y
+    auto push = [&](const int i, const unsigned long long hits, const int y) __attribute__((always_inline)) {
+        if (hits) {
+            const unsigned slot = lq_n[i] + __popcll(hits & ((1ull << lane) - 1ull));
+            if (((hits >> lane) & 1ull) && slot < PQ_CAP) lq[i][slot] = (unsigned)xq | ((unsigned)y << 16);
+            lq_n[i] += (unsigned)__popcll(hits);
+        }
+    };
+    unsigned pend = 0u; // plain detector: this lane's candidates of the row above (see below)
+
     // One chunk of 20 input rows, straight line.  Input row r of the strip
     // completes output row y0 + r - 18.
     auto chunk = [&](const int rb) __attribute__((always_inline)) {
@@ -481,18 +493,56 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
             // y mod 32 = 30) are left to alias_prefilter_kernel.  No global memory
             // is touched here, so the counted waits of the row loop stay exact.
             const int yo = y0 + r - 2 * RADIUS;
-            if (pre && valid && yo > 8 && yo < h - 8 && (plain || (yo & 31) < 31)) { // wave-uniform
-                const unsigned long long lanes = (!plain && (yo & 31) == 30) ? pre_mask0 : pre_mask;
+            const bool row_ok = pre && valid && yo > 8 && yo < h - 8 && (plain || (yo & 31) < 31); // wave-uniform
+            if constexpr (!PLAIN) {
+                if (row_ok) {
+                    const unsigned long long lanes = (yo & 31) == 30 ? pre_mask0 : pre_mask;
 #pragma unroll
-                for (int i = 0; i < S; ++i) {
-                    const unsigned long long hits = __ballot(fabsf(__fsub_rn(b[i + 1], b[i + 2])) > thr[i]) & lanes;
-                    if (hits) {
-                        const unsigned slot = lq_n[i] + __popcll(hits & ((1ull << lane) - 1ull));
-                        if (((hits >> lane) & 1ull) && slot < PQ_CAP)
-                            lq[i][slot] = (unsigned)xq | ((unsigned)yo << 16);
-                        lq_n[i] += (unsigned)__popcll(hits);
+                    for (int i = 0; i < S; ++i)
+                        push(i, __ballot(fabsf(__fsub_rn(b[i + 1], b[i + 2])) > thr[i]) & lanes, yo);
+                }
+            } else if (pre) { // wave-uniform
+                // The plain detector wants a strict extremum over 26 neighbours.  Being one
+                // among the four in-plane neighbours is necessary and leaves a fifteenth of
+                // the contrast candidates.  Left and right come from the lanes beside (lanes
+                // 0 and 63 have only one in this wave and pass), the row above from LDS, and
+                // the row below decides one row later: `pend` holds, per lane, which scales
+                // wait as a maximum (bit i) or a minimum (bit S + i).
+                float dn[S];
+#pragma unroll
+                for (int i = 0; i < S; ++i) dn[i] = __fsub_rn(b[i + 1], b[i + 2]);
+                if (__ballot(pend != 0u)) { // rare
+#pragma unroll
+                    for (int i = 0; i < S; ++i) {
+                        const float dp = d_up[i][lane];
+                        const bool keep = (((pend >> i) & 1u) && (!valid || dp > dn[i])) ||
+                                          (((pend >> (S + i)) & 1u) && (!valid || dp < dn[i]));
+                        push(i, __ballot(keep), yo - 1);
                     }
                 }
+                pend = 0u;
+                if (row_ok) {
+#pragma unroll
+                    for (int i = 0; i < S; ++i) {
+                        const float d = dn[i];
+                        const bool big = pre_lane && fabsf(d) > thr[i];
+                        if (__ballot(big)) { // wave-uniform: some lane passes the contrast test
+                            const float dl = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x138, 0xf, 0xf, false)); // lane - 1
+                            const float dr = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x130, 0xf, 0xf, false)); // lane + 1
+                            const bool edge = lane == 0 || lane == 63;
+                            bool is_max = big && ((d > dl && d > dr) || edge);
+                            bool is_min = big && ((d < dl && d < dr) || edge);
+                            if (r > 2 * RADIUS) { // the row above was completed by this wave
+                                const float du = d_up[i][lane];
+                                is_max = is_max && d > du;
+                                is_min = is_min && d < du;
+                            }
+                            pend |= (is_max ? 1u << i : 0u) | (is_min ? 1u << (S + i) : 0u);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < S; ++i) d_up[i][lane] = dn[i];
             }
         });
     };
@@ -536,9 +586,14 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     // counter state its own back edge produces, and the waits inside it are
     // exact on every trip.
     chunk(0);
-    for (int rb = COL_RING; rb < nin; rb += COL_RING) {
+    int rb = COL_RING;
+    for (; rb < nin; rb += COL_RING) {
         chunk(rb);
         flush_if_filling();
+    }
+    if (PLAIN && pre && __ballot(pend != 0u)) { // the strip's last row has no row below in this wave
+#pragma unroll
+        for (int i = 0; i < S; ++i) push(i, __ballot(((pend >> i) | (pend >> (S + i))) & 1u), y0 + rb - 2 * RADIUS - 1);
     }
     if (pre) flush();
 }
@@ -1267,10 +1322,21 @@ __global__ __launch_bounds__(256) void detect_lowe_kernel(
                 hv.xy = 0;
                 hv.sub = float4{0.f, 0.f, 0.f, 0.f};
                 if (x > 8 && x < w - 8 && y > 8 && y < h - 8) {
+                    // contrast, then the extremum along the row and along the column: each
+                    // test is necessary and discards most of what reaches it, before the
+                    // 27-cell cube is fetched
                     const float *c = blur0 + (i + 1) * plane + x + (long)p * y;
-                    if (fabsf(__fsub_rn(c[0], c[plane])) > a.pre_thresh)
-                        hit = lowe_candidate(blur0, plane, w, p, h, S, a.contrast, a.r_thresh, a.pre_thresh,
-                                             a.sigma, a.pix[oi], x, y, i, hv);
+                    const float v = __fsub_rn(c[0], c[plane]);
+                    if (fabsf(v) > a.pre_thresh) {
+                        const float l = __fsub_rn(c[-1], c[plane - 1]), r = __fsub_rn(c[1], c[plane + 1]);
+                        const bool is_max = v > l && v > r, is_min = v < l && v < r;
+                        if (is_max || is_min) {
+                            const float u = __fsub_rn(c[-p], c[plane - p]), d = __fsub_rn(c[p], c[plane + p]);
+                            if ((is_max && v > u && v > d) || (is_min && v < u && v < d))
+                                hit = lowe_candidate(blur0, plane, w, p, h, S, a.contrast, a.r_thresh,
+                                                     a.pre_thresh, a.sigma, a.pix[oi], x, y, i, hv);
+                        }
+                    }
                 }
                 append_lowe(hit, hv, lane, &counts[g], cand + (long)g * a.cap, sub + (long)g * a.cap, a.cap);
             }
@@ -2104,10 +2170,15 @@ int hl_pyramid(const void *src, int src_w, int src_h, int src_pitch, long src_st
     dim3 grid(idivup(w, 64), idivup(h, rows), nimg), block(64);
     hipStream_t s = (hipStream_t)stream;
     ScopedTimer t(4, s);
-#define PYR_LAUNCH(SS, MD)                                                                         \
-    hipLaunchKernelGGL((pyramid_kernel<SS, MD>), grid, block, 0, s, (const float *)src, src_w,     \
+#define PYR_LAUNCH_P(SS, MD, PL)                                                                   \
+    hipLaunchKernelGGL((pyramid_kernel<SS, MD, PL>), grid, block, 0, s, (const float *)src, src_w, \
                        src_h, src_pitch, src_stride, blur, blur_stride, w, p, h, rows, *taps,      \
-                       contrast, queue, queue_stride, qcount, qcount_stride, qcap, group0, plain)
+                       contrast, queue, queue_stride, qcount, qcount_stride, qcap, group0)
+#define PYR_LAUNCH(SS, MD)                                                                         \
+    do {                                                                                           \
+        if (plain) PYR_LAUNCH_P(SS, MD, true);                                                     \
+        else PYR_LAUNCH_P(SS, MD, false);                                                          \
+    } while (0)
     if (n_scales != 2 && n_scales != 3) return -1002;
     switch (src_mode + 3 * (n_scales - 2)) {
     case 0: PYR_LAUNCH(2, 0); break;
@@ -2118,6 +2189,7 @@ int hl_pyramid(const void *src, int src_w, int src_h, int src_pitch, long src_st
     default: PYR_LAUNCH(3, 2); break;
     }
 #undef PYR_LAUNCH
+#undef PYR_LAUNCH_P
     return launch_status();
 }
 
