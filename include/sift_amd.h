@@ -95,7 +95,12 @@ void copyDeviceData(float *dst, float *src, int width, int pitch, int height, vo
 void sift_default_params(sift_params *p);
 int sift_set_params(const sift_params *p); /* 0 = ok; rebuilds the tables */
 void sift_get_params(sift_params *p);
-/* message of the most recent failure on this thread's library state, "" if none */
+/* message of the calling thread's most recent failure, "" if none.
+ * Threading: calls on different devices (one host thread per GPU, each with its
+ * own current device) run side by side; calls on one device take turns, since
+ * they share that device's scratch arenas.  sift_set_params must not run while
+ * another thread extracts (the reference's tables are process-wide too,
+ * cudaSiftD.h:16-25). */
 const char *sift_last_error(void);
 void sift_clear_error(void);
 /* tap tables as the kernels receive them: blur[(S+3)*19], wnd[S*16], desc[16] */

@@ -46,7 +46,12 @@ typedef struct {
     void *last_stream;
 } slot_ctx;
 
+/* g_mu guards the parameters and tables; g_dev_mu[d] guards device d's slots, batch
+ * streams and counters.  Calls on different devices run side by side (one host
+ * thread per GPU), calls on one device take turns because they share its arenas.
+ * Parameters must not be changed while another thread extracts. */
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_mutex_t g_dev_mu[MAX_DEV] = {[0 ... MAX_DEV - 1] = PTHREAD_MUTEX_INITIALIZER};
 static sift_params g_params = {4, 2, 2500, 1.6f, 10.0f, 10.0f, 0, 0};
 static int g_tables_ready = 0;
 static float g_blur[HL_MAX_PLANES * HL_TAPS];
@@ -65,7 +70,7 @@ static int g_lanes = N_LANES;
 static unsigned *g_slot_counter[MAX_DEV]; /* device, SIFT_MAX_SLOTS words */
 static int g_chunk = 256;
 static int g_queue_cap = QUEUE_CAP; /* 0: no pre-filter, dense detector only */
-static char g_err[512] = "";
+static __thread char g_err[512] = ""; /* the calling thread's last error */
 
 static void set_err(const char *fmt, ...)
 {
@@ -86,6 +91,20 @@ static int fail_hl(int code, const char *what)
         set_err("%s: %s", what, hl_error_string(code));
     return code;
 }
+
+/* locks the calling thread's current device and returns its index, or -1 */
+static int lock_device(const char *who)
+{
+    const int dev = hl_get_device();
+    if (dev < 0 || dev >= MAX_DEV) {
+        set_err("%s: no usable HIP device", who);
+        return -1;
+    }
+    pthread_mutex_lock(&g_dev_mu[dev]);
+    return dev;
+}
+
+static void unlock_device(int dev) { pthread_mutex_unlock(&g_dev_mu[dev]); }
 
 static int idivup(int a, int b) { return (a % b != 0) ? (a / b + 1) : (a / b); }      /* utils.cc:59 */
 static int ialignup(int A, int a) { return (A % a != 0) ? (A + a - A % a) : A; }     /* utils.cc:60 */
@@ -138,6 +157,15 @@ static int build_tables(void)
     }
     g_tables_ready = 1;
     return 0;
+}
+
+static int tables_ok(void)
+{
+    int r = 0;
+    pthread_mutex_lock(&g_mu);
+    if (!g_tables_ready) r = build_tables();
+    pthread_mutex_unlock(&g_mu);
+    return r;
 }
 
 static float scale_value(int i, int octave) /* cudaSiftH.cu:94-95 */
@@ -195,8 +223,7 @@ void sift_get_params(sift_params *p) { *p = g_params; }
 
 void sift_get_tables(float *blur, float *wnd, float *desc)
 {
-    if (!g_tables_ready)
-        build_tables();
+    tables_ok();
     memcpy(blur, g_blur, sizeof(float) * (g_params.n_scales + 3) * HL_TAPS);
     memcpy(wnd, g_wnd, sizeof(float) * g_params.n_scales * 16);
     memcpy(desc, g_desc, sizeof(float) * 16);
@@ -227,9 +254,8 @@ static void free_slot(slot_ctx *c)
 
 void sift_shutdown(void)
 {
-    pthread_mutex_lock(&g_mu);
-    int dev = hl_get_device();
-    if (dev >= 0 && dev < MAX_DEV) {
+    const int dev = lock_device("sift_shutdown");
+    if (dev >= 0) {
         hl_device_sync();
         for (int s = 0; s < SIFT_MAX_SLOTS + N_LANES; ++s)
             free_slot(&g_slots[dev][s]);
@@ -252,8 +278,8 @@ void sift_shutdown(void)
             hl_free(g_slot_counter[dev]);
             g_slot_counter[dev] = NULL;
         }
+        unlock_device(dev);
     }
-    pthread_mutex_unlock(&g_mu);
 }
 
 static int ensure_slot_counter(int dev)
@@ -472,26 +498,25 @@ void initDeviceConstant(void)
 
 void initDeviceVariables(void)
 {
-    pthread_mutex_lock(&g_mu);
-    int dev = hl_get_device();
-    if (dev < 0 || dev >= MAX_DEV) {
-        set_err("no usable HIP device");
-    } else if (ensure_slot_counter(dev) == 0) {
+    const int dev = lock_device("initDeviceVariables");
+    if (dev < 0) return;
+    if (ensure_slot_counter(dev) == 0) {
         /* the reference's cudaMemcpyToSymbol is ordered after all earlier work */
         int r = hl_device_sync();
         if (!r) r = hl_memset_async(g_slot_counter[dev], 0, sizeof(unsigned) * SIFT_MAX_SLOTS, NULL);
         if (!r) r = hl_stream_sync(NULL);
         if (r) fail_hl(r, "initDeviceVariables");
     }
-    pthread_mutex_unlock(&g_mu);
+    unlock_device(dev);
 }
 
 void extractSift(SiftPoint *siftPt, float *d_src, int width, int pitch, int height, void *stream,
                  int streamIdx, int octaveIdx)
 {
-    pthread_mutex_lock(&g_mu);
+    const int dev = lock_device("extractSift");
+    if (dev < 0) return;
     do {
-        if (!g_tables_ready && build_tables())
+        if (tables_ok())
             break;
         if (!siftPt || !d_src || width < 1 || height < 1 || pitch < width) {
             set_err("extractSift: bad image arguments (w=%d pitch=%d h=%d)", width, pitch, height);
@@ -511,11 +536,6 @@ void extractSift(SiftPoint *siftPt, float *d_src, int width, int pitch, int heig
             set_err("extractSift: octaveIdx must be 0 when the first octave is up-sampled");
             break;
         }
-        int dev = hl_get_device();
-        if (dev < 0 || dev >= MAX_DEV) {
-            set_err("extractSift: no usable HIP device");
-            break;
-        }
         if (ensure_slot_counter(dev))
             break;
         slot_ctx *c = &g_slots[dev][streamIdx];
@@ -524,21 +544,17 @@ void extractSift(SiftPoint *siftPt, float *d_src, int width, int pitch, int heig
         enqueue_extract(c, siftPt, NULL, d_src, 0, 0, 1, pitch, octaveIdx,
                         g_slot_counter[dev] + streamIdx, stream);
     } while (0);
-    pthread_mutex_unlock(&g_mu);
+    unlock_device(dev);
 }
 
 int getPointCount(int streamIdx)
 {
     int result = -1;
-    pthread_mutex_lock(&g_mu);
+    const int dev = lock_device("getPointCount");
+    if (dev < 0) return -1;
     do {
         if (streamIdx < 0 || streamIdx >= SIFT_MAX_SLOTS) {
             set_err("getPointCount: streamIdx %d outside 0..%d", streamIdx, SIFT_MAX_SLOTS - 1);
-            break;
-        }
-        int dev = hl_get_device();
-        if (dev < 0 || dev >= MAX_DEV) {
-            set_err("getPointCount: no usable HIP device");
             break;
         }
         if (ensure_slot_counter(dev))
@@ -555,7 +571,7 @@ int getPointCount(int streamIdx)
         }
         result = (int)v;
     } while (0);
-    pthread_mutex_unlock(&g_mu);
+    unlock_device(dev);
     return result;
 }
 
@@ -587,9 +603,10 @@ static int extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
 {
     const long esz = imgs_u8 ? 1 : (long)sizeof(float);
     int rc = -1;
-    pthread_mutex_lock(&g_mu);
+    const int dev = lock_device("sift_extract_batch");
+    if (dev < 0) return -1;
     do {
-        if (!g_tables_ready && build_tables())
+        if (tables_ok())
             break;
         if (!d_pts || !d_imgs || !h_counts || n < 1 || width < 1 || height < 1 || pitch < width ||
             img_stride < (long)pitch * (height - 1) + width) {
@@ -598,11 +615,6 @@ static int extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
         }
         if (width > 65535 || height > 65535) {
             set_err("sift_extract_batch: image larger than 65535 pixels on a side");
-            break;
-        }
-        int dev = hl_get_device();
-        if (dev < 0 || dev >= MAX_DEV) {
-            set_err("sift_extract_batch: no usable HIP device");
             break;
         }
         const int chunk = n < g_chunk ? n : g_chunk;
@@ -667,7 +679,7 @@ static int extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
         }
         rc = 0;
     } while (0);
-    pthread_mutex_unlock(&g_mu);
+    unlock_device(dev);
     return rc;
 }
 
@@ -693,7 +705,7 @@ int sift_extract_batch_u8(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts
 /* ---- stage launchers (dense planes, reference layout) ------------------------ */
 static int stage_ok(const char *name, const void *a, const void *b, int w, int p, int h)
 {
-    if (!g_tables_ready && build_tables())
+    if (tables_ok())
         return 0;
     if (!a || !b || w < 1 || h < 1 || p < w) {
         set_err("%s: bad arguments (w=%d pitch=%d h=%d)", name, w, p, h);

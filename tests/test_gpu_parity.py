@@ -454,6 +454,44 @@ def test_full_size_1080p_three_scales(sift, oracle_mod):
     _assert_points_equal(oracle_mod, sift.points_to_numpy(d_pts, int(counts[0])), ref)
 
 
+def test_two_host_threads_share_a_device(sift, oracle_mod):
+    """Two host threads extract on one GPU at the same time, each on its own slot and stream
+    (the library takes the device's lock per call); both get the oracle's points, many times."""
+    import threading
+
+    pr = _params(sift, oracle_mod, n_scales=2, n_octaves=4, max_points=2500)
+    sift.initDeviceConstant()
+    sift.initDeviceVariables()
+    jobs = []
+    for slot, (w, h, seed) in enumerate([(640, 480, 11), (500, 375, 12)]):
+        img = sift.synth_image(w, h, seed=seed, dense=True)
+        ref, _, total = oracle_mod.extract(pr, img, w)
+        assert total == len(ref) > 100
+        jobs.append((slot, w, h, torch.from_numpy(img).cuda(), sift.new_point_buffer(), ref))
+    errors = []
+
+    def work(slot, w, h, d_img, pts, ref):
+        try:
+            stream = torch.cuda.Stream()
+            for _ in range(20):
+                sift.extractSift(pts, d_img, w, w, h, stream, slot, 0)
+                n = sift.getPointCount(slot)
+                # the slot's counter accumulates (cudaSiftH.cu:323-352): this call's points are the last len(ref)
+                got = sift.points_to_numpy(pts, n)[-len(ref):] if n <= 2500 else None
+                if n >= 2500:
+                    break
+                _assert_points_equal(oracle_mod, got, ref)
+        except Exception as e:  # noqa: BLE001
+            errors.append((slot, repr(e)))
+
+    threads = [threading.Thread(target=work, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_parameter_validation(sift):
     with pytest.raises(sift.SiftError):
         sift.set_params(profile=2)
