@@ -275,6 +275,36 @@ def test_sparse_and_dense_detectors_agree_on_random_shapes(sift, oracle_mod):
     assert len(dense) > 0
 
 
+def test_lowe_queue_and_dense_paths_agree_on_random_shapes(sift, oracle_mod):
+    """Profile "lowe": the queue path (the pyramid kernel's in-plane extremum pre-filter across
+    lanes, rows and strip borders, then the refinement kernel) against the dense detector and the
+    oracle, over random sizes, scales, thresholds and the doubled first octave."""
+    rng = np.random.default_rng(11)
+    total = 0
+    for case in range(14):
+        w, h = int(rng.integers(40, 700)), int(rng.integers(40, 900))
+        S = int(rng.integers(2, 4))
+        thr = float(rng.choice([2.0, 10.0, 25.0]))
+        up = int(case % 4 == 3)
+        kw = dict(n_scales=S, n_octaves=3, max_points=60000, extrema_thresh=thr, profile=1, upsample=up)
+        pr = _params(sift, oracle_mod, **kw)
+        img = sift.synth_image(w, h, seed=700 + case, dense=True)
+        ref, _, found = oracle_mod.extract(pr, img, w)
+        assert found == len(ref)
+        try:
+            sift.lib().sift_set_queue_cap(0)
+            dense = _extract_gpu(sift, img, w)
+            sift.lib().sift_set_queue_cap(65536)
+            sparse = _extract_gpu(sift, img, w)
+        finally:
+            sift.lib().sift_set_queue_cap(65536)
+            sift.set_params()
+        _assert_points_equal(oracle_mod, dense, ref)
+        _assert_points_equal(oracle_mod, sparse, ref)
+        total += len(ref)
+    assert total > 2000
+
+
 def test_u8_batch_entry_equals_float_entry(sift, oracle_mod):
     """8-bit images converted by the pyramid kernel's fetch: same bytes out as the float entry on
     the converted images, which the oracle pins; odd width and a pitch that is not a multiple of 4."""
