@@ -1166,9 +1166,35 @@ __device__ __forceinline__ bool lowe_candidate(const float *__restrict__ blur0, 
 {
     int c = i + 1;
     float d[3][3][3];
+    // The pixel's own row of the three DoG planes first (four cache lines instead of
+    // twelve): most candidates already fail against these eight neighbours.
+    {
+        const float *q = blur0 + (c - 1) * plane + x + (long)p * y;
+        float3u t[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) t[s] = *reinterpret_cast<const float3u *>(q + s * plane - 1);
+        float e[3][3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            e[s][0] = __fsub_rn(t[s].a, t[s + 1].a);
+            e[s][1] = __fsub_rn(t[s].b, t[s + 1].b);
+            e[s][2] = __fsub_rn(t[s].c, t[s + 1].c);
+        }
+        const float v0 = e[1][1];
+        if (!(fabsf(v0) > pre)) return false;
+        bool above = true, below = true;
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+                if (s != 1 || l != 1) {
+                    above = above && v0 > e[s][l];
+                    below = below && v0 < e[s][l];
+                }
+        if (!above && !below) return false;
+    }
     lowe_cube(blur0, plane, p, c, x, y, d);
     float v = d[1][1][1];
-    if (!(fabsf(v) > pre)) return false;
     bool above = true, below = true;
 #pragma unroll
     for (int s = 0; s < 3; ++s)
