@@ -137,6 +137,13 @@ void sift_set_batch_chunk(int images_per_launch);
  * 4096).  A queue that overflows is redone by the dense detector, so results do
  * not depend on n; 0 disables the queues (dense detector only). */
 void sift_set_queue_cap(int n);
+/* Diagnostics: after the work of slot streamIdx has completed (it is waited
+ * for), copies per (octave, scale) group, octave-major, the number of keypoints
+ * the group produced (before the cap) into accepted[] and the number of
+ * candidates the pyramid pass queued for it into queued[] (a value above the
+ * queue's capacity marks a group the dense detector redid).  Returns the number
+ * of groups written (at most n), or -1.  No counterpart in the reference. */
+int sift_get_group_counts(int streamIdx, unsigned *accepted, unsigned *queued, int n);
 /* launch sets in flight at once, each on a private stream and arena: 1 or 2
  * (default 2: the short kernels of the small octaves of one set overlap the
  * long kernels of the other) */

@@ -71,6 +71,7 @@ SYMBOLS = {
     "sift_set_batch_chunk": (None, [C.c_int]),
     "sift_set_batch_lanes": (None, [C.c_int]),
     "sift_set_queue_cap": (None, [C.c_int]),
+    "sift_get_group_counts": (C.c_int, [C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.c_int]),
     "sift_device_count": (C.c_int, []),
     "sift_set_device": (C.c_int, [C.c_int]),
     "sift_dev_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
@@ -235,6 +236,17 @@ def extractSift(siftPt, d_src, width, pitch, height, stream=None, streamIdx=0, o
     lib().extractSift(_dev_f32(siftPt), _dev_f32(d_src), width, pitch, height, _stream_ptr(stream),
                       streamIdx, octaveIdx)
     _check()
+
+
+def group_counts(streamIdx=0):
+    """(accepted, queued) per (octave, scale) group of the slot's last extraction."""
+    a = (C.c_uint * 32)()
+    q = (C.c_uint * 32)()
+    n = lib().sift_get_group_counts(streamIdx, a, q, 32)
+    if n < 0:
+        _check()
+        raise SiftError("sift_get_group_counts failed")
+    return list(a[:n]), list(q[:n])
 
 
 def getPointCount(streamIdx=0):

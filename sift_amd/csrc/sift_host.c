@@ -575,6 +575,38 @@ int getPointCount(int streamIdx)
     return result;
 }
 
+int sift_get_group_counts(int streamIdx, unsigned *accepted, unsigned *queued, int n)
+{
+    if (streamIdx < 0 || streamIdx >= SIFT_MAX_SLOTS || !accepted || !queued || n < 1) {
+        set_err("sift_get_group_counts: bad arguments");
+        return -1;
+    }
+    const int dev = lock_device("sift_get_group_counts");
+    if (dev < 0) return -1;
+    int result = -1;
+    slot_ctx *c = &g_slots[dev][streamIdx];
+    if (!c->valid) {
+        set_err("sift_get_group_counts: slot %d has not been used", streamIdx);
+    } else {
+        unsigned words[COUNT_WORDS];
+        int r = hl_stream_sync(c->last_stream);
+        if (!r) r = hl_memcpy_async(words, c->counts, sizeof words, 2, NULL);
+        if (!r) r = hl_stream_sync(NULL);
+        if (r) {
+            fail_hl(r, "sift_get_group_counts");
+        } else {
+            const int groups = c->n_oct * c->S;
+            result = groups < n ? groups : n;
+            for (int g = 0; g < result; ++g) {
+                accepted[g] = words[g];
+                queued[g] = words[HL_MAX_GROUPS + g];
+            }
+        }
+    }
+    unlock_device(dev);
+    return result;
+}
+
 /* ---- batch ------------------------------------------------------------------ */
 static int ensure_lanes(int dev)
 {

@@ -503,8 +503,9 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
                 }
             } else if (pre) { // wave-uniform
                 // The plain detector wants a strict extremum over 26 neighbours.  Being one
-                // among the four in-plane neighbours is necessary and leaves a fifteenth of
-                // the contrast candidates.  Left and right come from the lanes beside (lanes
+                // among the four in-plane neighbours and the two at the same pixel of the
+                // neighbouring DoG planes is necessary and leaves a few percent of the
+                // contrast candidates.  Left and right come from the lanes beside (lanes
                 // 0 and 63 have only one in this wave and pass), the row above from LDS, and
                 // the row below decides one row later: `pend` holds, per lane, which scales
                 // wait as a maximum (bit i) or a minimum (bit S + i).
@@ -532,6 +533,10 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
                             const bool edge = lane == 0 || lane == 63;
                             bool is_max = big && ((d > dl && d > dr) || edge);
                             bool is_min = big && ((d < dl && d < dr) || edge);
+                            // the same pixel one DoG plane down and up
+                            const float d_lo = __fsub_rn(b[i], b[i + 1]), d_hi = __fsub_rn(b[i + 2], b[i + 3]);
+                            is_max = is_max && d > d_lo && d > d_hi;
+                            is_min = is_min && d < d_lo && d < d_hi;
                             if (r > 2 * RADIUS) { // the row above was completed by this wave
                                 const float du = d_up[i][lane];
                                 is_max = is_max && d > du;
@@ -1274,39 +1279,50 @@ __device__ __forceinline__ void append_lowe(bool hit, const LoweHit &hv, int lan
     }
 }
 
-// Queue-driven: one thread per contrast candidate queued by pyramid_kernel.
-// blockIdx.y = (octave, scale) group.
+// Queue-driven: one thread per candidate queued by pyramid_kernel.  The queues
+// of all (octave, scale) groups of an image form one list of 64-candidate items,
+// which the image's waves (gridDim.x blocks of one wave) take in turn: the launch
+// has the same few thousand waves whatever the images hold, and each wave's share
+// is even.  (A block per group and queue segment is mostly blocks that find
+// nothing to do, and their dispatch alone outlasts the useful work.)
 template <int S>
-__global__ __launch_bounds__(256) void verify_lowe_kernel(
+__global__ __launch_bounds__(64) void verify_lowe_kernel(
     const float *__restrict__ arena, long arena_stride, const unsigned *queue, long queue_stride,
     const unsigned *qcount, long qcount_stride, unsigned *cand, float4 *sub, long cand_stride,
     unsigned *counts, long counts_stride, hl_detect_args a)
 {
-    const int lane = threadIdx.x & 63;
-    const int g = blockIdx.y, z = blockIdx.z;
-    const int oi = g / S, i = g - oi * S;
-    const hl_octave oc = a.oct[oi];
-    const unsigned n = qcount[z * qcount_stride + g];
-    if (n == 0 || n > (unsigned)oc.qcap) return; // overflow: the dense kernel takes this group
-    const long plane = (long)oc.p * oc.h;
-    const float *blur0 = arena + z * arena_stride + oc.blur_off;
-    queue += z * queue_stride + oc.queue_off + (long)i * oc.qcap;
-    cand += z * cand_stride + (long)g * a.cap;
-    sub += z * cand_stride + (long)g * a.cap;
-    counts += z * counts_stride + g;
-    const unsigned step = gridDim.x * 256;
-    for (unsigned e0 = blockIdx.x * 256; e0 < n; e0 += step) { // block-uniform trip count
-        const unsigned e = e0 + threadIdx.x;
+    const int lane = threadIdx.x;
+    const int z = blockIdx.y;
+    qcount += z * qcount_stride;
+    const int n_groups = a.n_oct * S;
+    // items per group (none for an overflowed queue: the dense kernel takes that group)
+    unsigned first[HL_MAX_GROUPS + 1];
+    first[0] = 0;
+    for (int g = 0; g < n_groups; ++g) {
+        const unsigned n = qcount[g];
+        first[g + 1] = first[g] + (n > (unsigned)a.oct[g / S].qcap ? 0u : (n + 63u) / 64u);
+    }
+    const unsigned total = first[n_groups];
+    int g = 0;
+    for (unsigned item = blockIdx.x; item < total; item += gridDim.x) { // wave-uniform
+        while (item >= first[g + 1]) ++g;
+        const int oi = g / S, i = g - oi * S;
+        const hl_octave oc = a.oct[oi];
+        const unsigned n = qcount[g];
+        const long plane = (long)oc.p * oc.h;
+        const float *blur0 = arena + z * arena_stride + oc.blur_off;
+        const unsigned e = (item - first[g]) * 64u + lane;
         bool hit = false;
         LoweHit hv;
         hv.xy = 0;
         hv.sub = float4{0.f, 0.f, 0.f, 0.f};
         if (e < n) {
-            const unsigned xy = queue[e];
+            const unsigned xy = queue[z * queue_stride + oc.queue_off + (long)i * oc.qcap + e];
             hit = lowe_candidate(blur0, plane, oc.w, oc.p, oc.h, S, a.contrast, a.r_thresh, a.pre_thresh,
                                  a.sigma, a.pix[oi], (int)(xy & 0xffffu), (int)(xy >> 16), i, hv);
         }
-        append_lowe(hit, hv, lane, counts, cand, sub, a.cap);
+        append_lowe(hit, hv, lane, counts + z * counts_stride + g, cand + z * cand_stride + (long)g * a.cap,
+                    sub + z * cand_stride + (long)g * a.cap, a.cap);
     }
 }
 
@@ -2298,7 +2314,10 @@ int hl_verify_lowe(const float *arena, long arena_stride, const unsigned *queue,
                    int nimg, void *stream)
 {
     if (!detect_args_ok(a, nimg) || !sub) return -1001;
-    dim3 grid(8, a->n_oct * a->n_scales, nimg), block(256);
+    // waves per image: enough for a few thousand waves per launch, which the chip holds at once
+    int per_image = 8192 / nimg;
+    per_image = per_image < 4 ? 4 : (per_image > 256 ? 256 : per_image);
+    dim3 grid(per_image, nimg), block(64);
     hipStream_t s = (hipStream_t)stream;
     ScopedTimer t(5, s);
     if (a->n_scales == 2)
