@@ -1295,12 +1295,23 @@ __global__ __launch_bounds__(64) void verify_lowe_kernel(
     const int z = blockIdx.y;
     qcount += z * qcount_stride;
     const int n_groups = a.n_oct * S;
-    // items per group (none for an overflowed queue: the dense kernel takes that group)
-    unsigned first[HL_MAX_GROUPS + 1];
-    first[0] = 0;
-    for (int g = 0; g < n_groups; ++g) {
-        const unsigned n = qcount[g];
-        first[g + 1] = first[g] + (n > (unsigned)a.oct[g / S].qcap ? 0u : (n + 63u) / 64u);
+    // first[g]: index of group g's first item (an overflowed queue has none: the dense
+    // kernel takes that group).  Lane g counts group g, a wave scan adds them up.
+    __shared__ unsigned first[HL_MAX_GROUPS + 1];
+    {
+        unsigned items = 0;
+        if (lane < n_groups) {
+            const unsigned n = qcount[lane];
+            items = n > (unsigned)a.oct[lane / S].qcap ? 0u : (n + 63u) / 64u;
+        }
+#pragma unroll
+        for (int off = 1; off < HL_MAX_GROUPS; off <<= 1) {
+            const unsigned up = __shfl_up(items, off);
+            if (lane >= off) items += up;
+        }
+        if (lane == 0) first[0] = 0;
+        if (lane < HL_MAX_GROUPS) first[lane + 1] = items;
+        __syncthreads();
     }
     const unsigned total = first[n_groups];
     int g = 0;
