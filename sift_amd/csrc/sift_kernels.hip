@@ -838,7 +838,12 @@ __global__ __launch_bounds__(256) void alias_prefilter_kernel(const float *__res
 }
 
 // Sparse detector: consumes the contrast candidates queued by pyramid_kernel
-// and alias_prefilter_kernel.  blockIdx.y = (octave, scale) group.
+// and alias_prefilter_kernel.  The queues of all (octave, scale) groups of an
+// image form one list of 256-candidate items which the image's blocks
+// (gridDim.x of them) take in turn, so the launch has the same number of blocks
+// whatever the images hold and each block's share is even.  (A block per group
+// and queue segment is mostly blocks that find nothing to do, and their
+// dispatch alone outlasts the useful work.)
 template <int S>
 __global__ __launch_bounds__(256) void verify_kernel(const float *__restrict__ arena, long arena_stride,
                                                      const unsigned *queue, long queue_stride,
@@ -848,47 +853,78 @@ __global__ __launch_bounds__(256) void verify_kernel(const float *__restrict__ a
                                                      hl_detect_args a)
 {
     const int lane = threadIdx.x & 63;
-    const int g = blockIdx.y, z = blockIdx.z;
-    const int oi = g / S, i = g - oi * S;
-    const hl_octave oc = a.oct[oi];
-    const unsigned n = qcount[z * qcount_stride + g];
-    if (n == 0 || n > (unsigned)oc.qcap) return; // overflow: the dense kernel takes this group
-    const long plane = (long)oc.p * oc.h;
-    const float *b3 = arena + z * arena_stride + oc.blur_off + i * plane; // blur planes i..i+3
-    queue += z * queue_stride + oc.queue_off + (long)i * oc.qcap;
-    cand += z * cand_stride + (long)g * a.cap;
-    counts += z * counts_stride + g;
+    const int z = blockIdx.y;
+    qcount += z * qcount_stride;
+    const int n_groups = a.n_oct * S;
+    // first[g]: index of group g's first item (an overflowed queue has none: the dense
+    // kernel takes that group).  Lane g of the first wave counts group g, a wave scan adds up.
+    __shared__ unsigned first[HL_MAX_GROUPS + 1];
     // Candidates that need the tile addressing (a tenth of them, spread over
     // every wave) are set aside in LDS and handled in full batches, so that the
     // long path runs once per 256 of them instead of once per wave.
     __shared__ unsigned slow_xy[512];
     __shared__ unsigned slow_n;
-    if (threadIdx.x == 0) slow_n = 0;
+    if (threadIdx.x < 64) {
+        unsigned items = 0;
+        if (lane < n_groups) {
+            const unsigned n = qcount[lane];
+            items = n > (unsigned)a.oct[lane / S].qcap ? 0u : (n + 255u) / 256u;
+        }
+#pragma unroll
+        for (int off = 1; off < HL_MAX_GROUPS; off <<= 1) {
+            const unsigned up = __shfl_up(items, off);
+            if (lane >= off) items += up;
+        }
+        if (lane == 0) first[0] = 0, slow_n = 0;
+        if (lane < HL_MAX_GROUPS) first[lane + 1] = items;
+    }
     __syncthreads();
-    auto run_slow = [&](unsigned first, unsigned count) __attribute__((always_inline)) { // block-uniform arguments
+    const unsigned total = first[n_groups];
+    int g = 0, g_slow = -1; // g_slow: the group the set-aside candidates belong to
+    // the set-aside candidates of group gs, `count` of them from slot `from` (block-uniform arguments)
+    auto run_slow = [&](const int gs, const unsigned from, const unsigned count) __attribute__((always_inline)) {
+        const int oi = gs / S, i = gs - oi * S;
+        const hl_octave oc = a.oct[oi];
+        const long plane = (long)oc.p * oc.h;
+        const float *b3 = arena + z * arena_stride + oc.blur_off + i * plane;
         bool hit = false;
         unsigned xy = 0;
         if (threadIdx.x < count) {
-            xy = slow_xy[first + threadIdx.x];
+            xy = slow_xy[from + threadIdx.x];
             hit = accept_candidate<false>(b3, plane, oc.w, oc.p, oc.h, a.edge_limit, (int)(xy & 0xffffu),
                                           (int)(xy >> 16));
         }
-        append_hits(hit, xy, lane, counts, cand, a.cap);
+        append_hits(hit, xy, lane, counts + z * counts_stride + gs, cand + z * cand_stride + (long)gs * a.cap, a.cap);
     };
-    const unsigned step = gridDim.x * 256;
-    for (unsigned e0 = blockIdx.x * 256; e0 < n; e0 += step) { // block-uniform trip count
-        const unsigned e = e0 + threadIdx.x;
+    for (unsigned item = blockIdx.x; item < total; item += gridDim.x) { // block-uniform
+        while (item >= first[g + 1]) ++g;
+        if (g != g_slow) { // a new group: finish what the last one set aside
+            const unsigned pending = slow_n;
+            __syncthreads();
+            if (pending) {
+                run_slow(g_slow, 0, pending);
+                if (threadIdx.x == 0) slow_n = 0;
+                __syncthreads();
+            }
+            g_slow = g;
+        }
+        const int oi = g / S, i = g - oi * S;
+        const hl_octave oc = a.oct[oi];
+        const unsigned n = qcount[g];
+        const long plane = (long)oc.p * oc.h;
+        const float *b3 = arena + z * arena_stride + oc.blur_off + i * plane; // blur planes i..i+3
+        const unsigned e = (item - first[g]) * 256u + threadIdx.x;
         bool hit = false, slow = false;
         unsigned xy = 0;
         if (e < n) {
-            xy = queue[e];
+            xy = queue[z * queue_stride + oc.queue_off + (long)i * oc.qcap + e];
             const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
             if (candidate_is_plain(oc.w, oc.h, x, y))
                 hit = accept_candidate<true>(b3, plane, oc.w, oc.p, oc.h, a.edge_limit, x, y);
             else
                 slow = true;
         }
-        append_hits(hit, xy, lane, counts, cand, a.cap);
+        append_hits(hit, xy, lane, counts + z * counts_stride + g, cand + z * cand_stride + (long)g * a.cap, a.cap);
         const unsigned long long sm = __ballot(slow);
         if (sm) {
             unsigned base = 0;
@@ -899,14 +935,14 @@ __global__ __launch_bounds__(256) void verify_kernel(const float *__restrict__ a
         __syncthreads();
         const unsigned pending = slow_n; // at most 255 kept + 256 new
         if (pending >= 256) {
-            run_slow(pending - 256, 256);
+            run_slow(g, pending - 256, 256);
             __syncthreads();
             if (threadIdx.x == 0) slow_n = pending - 256;
             __syncthreads();
         }
     }
     const unsigned pending = slow_n;
-    if (pending) run_slow(0, pending);
+    if (pending) run_slow(g_slow, 0, pending);
 }
 
 // Dense detector: the reference's kernel as it stands.  One block per 96 x 32
@@ -2280,7 +2316,10 @@ int hl_verify(const float *arena, long arena_stride, const unsigned *queue, long
               unsigned *counts, long counts_stride, const hl_detect_args *a, int nimg, void *stream)
 {
     if (!detect_args_ok(a, nimg)) return -1001;
-    dim3 grid(8, a->n_oct * a->n_scales, nimg), block(256);
+    // blocks per image: enough for a few thousand waves per launch, which the chip holds at once
+    int per_image = 2048 / nimg;
+    per_image = per_image < 2 ? 2 : (per_image > 64 ? 64 : per_image);
+    dim3 grid(per_image, nimg), block(256);
     hipStream_t s = (hipStream_t)stream;
     ScopedTimer t(5, s);
     if (a->n_scales == 2)
