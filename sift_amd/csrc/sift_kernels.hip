@@ -2317,7 +2317,7 @@ int hl_verify(const float *arena, long arena_stride, const unsigned *queue, long
 {
     if (!detect_args_ok(a, nimg)) return -1001;
     // blocks per image: enough for a few thousand waves per launch, which the chip holds at once
-    int per_image = 2048 / nimg;
+    int per_image = 1024 / nimg;
     per_image = per_image < 2 ? 2 : (per_image > 64 ? 64 : per_image);
     dim3 grid(per_image, nimg), block(256);
     hipStream_t s = (hipStream_t)stream;
@@ -2365,7 +2365,7 @@ int hl_verify_lowe(const float *arena, long arena_stride, const unsigned *queue,
 {
     if (!detect_args_ok(a, nimg) || !sub) return -1001;
     // waves per image: enough for a few thousand waves per launch, which the chip holds at once
-    int per_image = 8192 / nimg;
+    int per_image = 4096 / nimg;
     per_image = per_image < 4 ? 4 : (per_image > 256 ? 256 : per_image);
     dim3 grid(per_image, nimg), block(64);
     hipStream_t s = (hipStream_t)stream;
