@@ -2429,7 +2429,11 @@ int hl_keypoints(void *pts, long pts_stride_points, unsigned char *meta, const f
 {
     if (nimg <= 0 || args->n_groups <= 0 || args->n_groups > HL_MAX_GROUPS) return -1001;
     // one wave per keypoint, grid-stride: the count is only known on the device
-    int gx = args->cap < 512 ? args->cap : 512;
+    // waves per image: the launch should be a few tens of thousands of waves (blocks that
+    // find no keypoint left still cost their dispatch), a single image still fills the chip
+    int gx = 32768 / nimg;
+    gx = gx < 16 ? 16 : (gx > 2048 ? 2048 : gx);
+    if (gx > args->cap) gx = args->cap;
     if (gx < 1) gx = 1;
     dim3 grid(gx, nimg), block(64);
     hipStream_t s = (hipStream_t)stream;
