@@ -2246,7 +2246,7 @@ int hl_pyramid(const void *src, int src_w, int src_h, int src_pitch, long src_st
     // tall as the launch allows while still giving the chip a few waves per SIMD, and
     // equal in height so that no strip is a short left-over
     int m = 11;
-    while (m > 2 && (long)idivup(w, 64) * idivup(h, COL_RING * m - 2 * RADIUS) * nimg < 6144) --m;
+    while (m > 2 && (long)idivup(w, 64) * idivup(h, COL_RING * m - 2 * RADIUS) * nimg < 4096) --m;
     // a launch that cannot fill the chip anyway (single small images) is bound by
     // the length of one strip walk: two output rows per strip halve it once more
     if (m == 2 && (long)idivup(w, 64) * idivup(h, COL_RING * 2 - 2 * RADIUS) * nimg < 1024) m = 1;
