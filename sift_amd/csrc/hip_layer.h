@@ -49,7 +49,7 @@ typedef struct {
     float sigma;        /* base sigma */
     float pix[HL_MAX_OCT]; /* input pixels per pixel of each octave (a power of two) */
     hl_octave oct[HL_MAX_OCT];
-    int band0[HL_MAX_OCT + 1];  /* first 32-row band of each octave (alias pre-filter units) */
+    int band0[HL_MAX_OCT + 1];  /* first alias pre-filter unit of each octave (units: 32 rows x 256 columns) */
     int dense0[HL_MAX_OCT + 1]; /* first 96x32-pixel block of each octave (dense detector units) */
 } hl_detect_args;
 

@@ -417,7 +417,7 @@ static int enqueue_extract(slot_ctx *c, SiftPoint *pts, unsigned char *meta, con
         da.oct[oi].blur_off = c->blur_off[oi];
         da.oct[oi].queue_off = c->queue_off[oi];
         da.pix[oi] = pix;
-        da.band0[oi + 1] = da.band0[oi] + idivup(hh, 32);
+        da.band0[oi + 1] = da.band0[oi] + idivup(hh, 32) * idivup(ww, 256);
         da.dense0[oi + 1] = da.dense0[oi] + idivup(ww, 96) * idivup(hh, 32);
         unsigned *q = prefilter ? c->queue + c->queue_off[oi] : NULL;
         if (oi == 0 && up)

@@ -783,14 +783,15 @@ __global__ __launch_bounds__(256) void alias_prefilter_kernel(const float *__res
                                                               long qcount_stride, hl_detect_args a)
 {
     const int lane = threadIdx.x & 63;
-    const int unit = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (unit >= a.band0[a.n_oct]) return; // whole wave; no barrier in this kernel
     const int oi = find_octave(a.band0, a.n_oct, unit);
     const hl_octave oc = a.oct[oi];
     const int w = oc.w, h = oc.h, p = oc.p;
-    const int xs4 = blockIdx.x * 256 + 4 * lane;
-    if (blockIdx.x * 256 >= w) return; // wave-uniform
-    const int yC = (unit - a.band0[oi]) * 32, yA = yC - 1; // row 0 is a source row too (targets at y = 31)
+    // a unit is one band of 32 rows by 256 columns; an octave's units are numbered row-major
+    const int xchunks = (w + 255) / 256, u = unit - a.band0[oi];
+    const int xs4 = (u % xchunks) * 256 + 4 * lane;
+    const int yC = (u / xchunks) * 32, yA = yC - 1; // row 0 is a source row too (targets at y = 31)
     const int z = blockIdx.z;
     const long plane = (long)p * h;
     const float *blur = arena + z * arena_stride + oc.blur_off;
@@ -2299,7 +2300,7 @@ int hl_alias_prefilter(const float *arena, long arena_stride, unsigned *queue, l
                        void *stream)
 {
     if (!detect_args_ok(a, nimg) || (arena_stride & 3) || (((size_t)arena) & 15)) return -1001;
-    dim3 grid(idivup(a->oct[0].w, 256), idivup(a->band0[a->n_oct], 4), nimg), block(256);
+    dim3 grid(idivup(a->band0[a->n_oct], 4), 1, nimg), block(256);
     hipStream_t s = (hipStream_t)stream;
     ScopedTimer t(6, s);
     if (a->n_scales == 2)
