@@ -522,6 +522,42 @@ def test_two_host_threads_share_a_device(sift, oracle_mod):
     assert not errors, errors
 
 
+@pytest.mark.parametrize("profile", [0, 1])
+@pytest.mark.parametrize("kind", ["flat", "checker", "noise", "steps", "huge_values", "ramp"])
+def test_degenerate_content(sift, oracle_mod, kind, profile):
+    """Images that are all of one kind: nothing to find (flat, ramp), a candidate at every pixel
+    (checkerboard, full-range noise: every queue and list overflows), divisions by zero in the
+    edge test (steps) and values far outside 0..255.  Same bits as the oracle, no error."""
+    w, h = 300, 220
+    rng = np.random.default_rng(99)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = {
+        "flat": np.full((h, w), 77.0),
+        "checker": 255.0 * (((xx // 3) + (yy // 3)) % 2),
+        "noise": rng.integers(0, 256, (h, w)).astype(np.float64),
+        "steps": 200.0 * ((xx // 40) % 2) + 30.0 * ((yy // 25) % 2),
+        "huge_values": 1.0e6 * np.sin(xx / 7.0) * np.cos(yy / 5.0) - 3.0e5,
+        "ramp": 0.5 * xx + 0.25 * yy,
+    }[kind].astype(np.float32)
+    kw = dict(n_scales=2, n_octaves=3, max_points=3000, profile=profile)
+    pr = _params(sift, oracle_mod, **kw)
+    ref, _, total = oracle_mod.extract(pr, img, w)
+    try:
+        got = _extract_gpu(sift, img, w)
+    finally:
+        sift.set_params()
+    if kind in ("flat", "ramp"):
+        assert len(ref) == 0
+    if total <= 3000:
+        _assert_points_equal(oracle_mod, got, ref)
+    else:  # over the cap: a subset of what the oracle finds without a cap
+        assert len(got) == 3000
+        pr_all = oracle_mod.params(**dict(kw, max_points=200000))
+        every, _, _ = oracle_mod.extract(pr_all, img, w)
+        have = {r.tobytes() for r in every}
+        assert all(r.tobytes() in have for r in got)
+
+
 def test_parameter_validation(sift):
     with pytest.raises(sift.SiftError):
         sift.set_params(profile=2)
