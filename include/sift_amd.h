@@ -124,6 +124,15 @@ int sift_extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
 int sift_extract_batch_u8(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
                           const unsigned char *d_imgs, long img_stride, int n,
                           int width, int pitch, int height, void *stream);
+/* The same without the wait: the counts go to d_counts (device, n words), the
+ * call returns as soon as the work is queued, and everything is ordered on
+ * `stream` (work queued on it before the call is waited for; work queued on it
+ * after the call sees the results).  imgs_u8 != 0: 8-bit images as above.  For
+ * callers that keep the link and the GPU busy at the same time: upload batch
+ * k+1 on a copy stream while batch k runs, read counts and points back later. */
+int sift_extract_batch_async(SiftPoint *d_pts, unsigned char *d_meta, unsigned *d_counts,
+                             const void *d_imgs, int imgs_u8, long img_stride, int n,
+                             int width, int pitch, int height, void *stream);
 /* 8-bit descriptors (no counterpart in the reference, whose descriptors are
  * float and L1-normalised, cudaSiftD.cu:186-200): d_out[128*j + k] =
  * min(255, round(512 * d_pts[j].data[k])) for the first n points.  Asynchronous

@@ -67,6 +67,8 @@ SYMBOLS = {
     "sift_shutdown": (None, []),
     "sift_extract_batch": (C.c_int, [_vp, _vp, _ip, _vp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "sift_extract_batch_u8": (C.c_int, [_vp, _vp, _ip, _vp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "sift_extract_batch_async": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, _vp]),
     "sift_quantize_descriptors": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "sift_set_batch_chunk": (None, [C.c_int]),
     "sift_set_batch_lanes": (None, [C.c_int]),
@@ -311,6 +313,24 @@ def extract_batch(d_imgs, width, want_meta=False, stream=None, d_pts=None):
                _stream_ptr(stream))
     _ok(rc)
     return (d_pts, counts, meta) if want_meta else (d_pts, counts)
+
+
+def extract_batch_async(d_imgs, width, d_pts, d_counts, stream=None, d_meta=None):
+    """extract_batch without the wait: counts go to d_counts (int32 CUDA tensor of n), nothing is
+    read back; ordered on `stream` (None: torch's current stream)."""
+    import torch
+
+    if d_imgs.dim() != 3 or d_imgs.dtype not in (torch.float32, torch.uint8) or not d_imgs.is_cuda \
+            or not d_imgs.is_contiguous():
+        raise SiftError("expected a contiguous (n, height, pitch) float32 or uint8 CUDA tensor")
+    n, h, p = d_imgs.shape
+    if d_counts.dtype != torch.int32 or d_counts.numel() < n or not d_counts.is_cuda:
+        raise SiftError("d_counts: int32 CUDA tensor with one entry per image")
+    if d_pts.numel() < n * get_params().max_points * POINT_FLOATS:
+        raise SiftError("d_pts is too small")
+    _ok(lib().sift_extract_batch_async(_dev_f32(d_pts), C.c_void_p(d_meta.data_ptr()) if d_meta is not None else None,
+                                       C.c_void_p(d_counts.data_ptr()), C.c_void_p(d_imgs.data_ptr()),
+                                       int(d_imgs.dtype == torch.uint8), h * p, n, width, p, h, _stream_ptr(stream)))
 
 
 def quantize_descriptors(d_pts, n, stream=None):

@@ -629,9 +629,11 @@ void sift_set_batch_lanes(int n)
         g_lanes = n;
 }
 
-static int extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts, const void *d_imgs,
-                         int imgs_u8, long img_stride, int n, int width, int pitch, int height,
-                         void *stream)
+/* h_counts != NULL: the counts go to the host and the call blocks until they are there.
+ * Otherwise they go to d_counts (device, n words) and the call returns after enqueueing. */
+static int extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts, unsigned *d_counts,
+                         const void *d_imgs, int imgs_u8, long img_stride, int n, int width, int pitch,
+                         int height, void *stream)
 {
     const long esz = imgs_u8 ? 1 : (long)sizeof(float);
     int rc = -1;
@@ -640,7 +642,7 @@ static int extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
     do {
         if (tables_ok())
             break;
-        if (!d_pts || !d_imgs || !h_counts || n < 1 || width < 1 || height < 1 || pitch < width ||
+        if (!d_pts || !d_imgs || (!h_counts && !d_counts) || n < 1 || width < 1 || height < 1 || pitch < width ||
             img_stride < (long)pitch * (height - 1) + width) {
             set_err("sift_extract_batch: bad arguments");
             break;
@@ -659,7 +661,7 @@ static int extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
             bad = ensure_arena(&g_slots[dev][BATCH_SLOT + l], width, height, 0, chunk);
         if (bad)
             break;
-        if (g_batch_count_n[dev] < n) {
+        if (!d_counts && g_batch_count_n[dev] < n) {
             if (g_batch_count[dev]) {
                 hl_device_sync();
                 hl_free(g_batch_count[dev]);
@@ -675,7 +677,7 @@ static int extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
             g_batch_count[dev] = (unsigned *)p;
             g_batch_count_n[dev] = n;
         }
-        unsigned *bc = g_batch_count[dev];
+        unsigned *bc = d_counts ? d_counts : g_batch_count[dev];
         int r = hl_memset_async(bc, 0, sizeof(unsigned) * (size_t)n, stream);
         /* fork: the private streams start after everything queued on the caller's stream */
         if (!r) r = hl_event_record(g_lane_event[dev][N_LANES], stream);
@@ -703,8 +705,10 @@ static int extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
         }
         if (bad)
             break;
-        if (!r) r = hl_memcpy_async(h_counts, bc, sizeof(unsigned) * (size_t)n, 2, stream);
-        if (!r) r = hl_stream_sync(stream);
+        if (!r && h_counts) {
+            r = hl_memcpy_async(h_counts, bc, sizeof(unsigned) * (size_t)n, 2, stream);
+            if (!r) r = hl_stream_sync(stream);
+        }
         if (r) {
             fail_hl(r, "finishing batch");
             break;
@@ -724,14 +728,26 @@ int sift_quantize_descriptors(const SiftPoint *d_pts, int n, unsigned char *d_ou
 int sift_extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts, const float *d_imgs,
                        long img_stride, int n, int width, int pitch, int height, void *stream)
 {
-    return extract_batch(d_pts, d_meta, h_counts, d_imgs, 0, img_stride, n, width, pitch, height, stream);
+    return extract_batch(d_pts, d_meta, h_counts, NULL, d_imgs, 0, img_stride, n, width, pitch, height, stream);
+}
+
+int sift_extract_batch_async(SiftPoint *d_pts, unsigned char *d_meta, unsigned *d_counts, const void *d_imgs,
+                             int imgs_u8, long img_stride, int n, int width, int pitch, int height,
+                             void *stream)
+{
+    if (!d_counts) {
+        set_err("sift_extract_batch_async: d_counts is NULL");
+        return -1;
+    }
+    return extract_batch(d_pts, d_meta, NULL, d_counts, d_imgs, imgs_u8 != 0, img_stride, n, width, pitch,
+                         height, stream);
 }
 
 int sift_extract_batch_u8(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
                           const unsigned char *d_imgs, long img_stride, int n, int width, int pitch,
                           int height, void *stream)
 {
-    return extract_batch(d_pts, d_meta, h_counts, d_imgs, 1, img_stride, n, width, pitch, height, stream);
+    return extract_batch(d_pts, d_meta, h_counts, NULL, d_imgs, 1, img_stride, n, width, pitch, height, stream);
 }
 
 /* ---- stage launchers (dense planes, reference layout) ------------------------ */

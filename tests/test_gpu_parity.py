@@ -558,6 +558,37 @@ def test_degenerate_content(sift, oracle_mod, kind, profile):
         assert all(r.tobytes() in have for r in got)
 
 
+def test_async_batch_entry_is_ordered_on_the_callers_stream(sift, oracle_mod):
+    """sift_extract_batch_async: two batches queued back to back on one stream, uploads queued
+    in between, no host wait until the end; each equals the blocking entry's result."""
+    sift.set_params(n_scales=2, n_octaves=4, max_points=1500)
+    cap, n, w, h = 1500, 6, 320, 240
+    host = [np.stack([sift.synth_image(w, h, seed=900 + 10 * b + i, dense=True) for i in range(n)]) for b in range(2)]
+    want = []
+    for b in range(2):
+        pts, counts = sift.extract_batch(torch.from_numpy(host[b]).cuda(), w)
+        want.append((pts.cpu().numpy().copy(), counts.copy()))
+    stream = torch.cuda.Stream()
+    pinned = [torch.from_numpy(x).pin_memory() for x in host]
+    d_img = [torch.empty((n, h, w), dtype=torch.float32, device="cuda") for _ in range(2)]
+    d_pts = [torch.full((n * cap, sift.POINT_FLOATS), float("nan"), dtype=torch.float32, device="cuda") for _ in range(2)]
+    d_cnt = [torch.full((n,), -1, dtype=torch.int32, device="cuda") for _ in range(2)]
+    with torch.cuda.stream(stream):
+        for b in range(2):
+            d_img[b].copy_(pinned[b], non_blocking=True)
+            sift.extract_batch_async(d_img[b], w, d_pts[b], d_cnt[b], stream=stream)
+    stream.synchronize()
+    for b in range(2):
+        counts = d_cnt[b].cpu().numpy()
+        assert np.array_equal(counts, want[b][1])
+        got = d_pts[b].cpu().numpy()
+        for i in range(n):
+            a = sift.points_to_numpy(torch.from_numpy(got), int(counts[i]), offset=i * cap)
+            r = sift.points_to_numpy(torch.from_numpy(want[b][0]), int(counts[i]), offset=i * cap)
+            assert oracle_mod.sort_points(a).tobytes() == oracle_mod.sort_points(r).tobytes()
+    sift.set_params()
+
+
 def test_parameter_validation(sift):
     with pytest.raises(sift.SiftError):
         sift.set_params(profile=2)
