@@ -16,6 +16,11 @@ What each file pins:
   extract_640x480_S3.npz         oracle keypoints for the synthetic 640x480, 3 scales,
                                  4 octaves, seed 1 image.  Oracle-generated: a regression
                                  anchor, not a reference output (the reference cannot run here).
+  extract_lowe_400x300_up.npz    the same for profile "lowe" with the doubled first octave
+                                 (400x300, 2 scales, 3 + 1 octaves, seed 3): an anchor against the
+                                 build's own definition drifting; nothing in the reference defines it.
+
+`python tests/golden/make_golden.py lowe` rewrites only the last one.
 """
 import hashlib
 import os
@@ -39,7 +44,24 @@ def hexrow(a):
     return " ".join(float(v).hex() for v in np.asarray(a, np.float32).ravel())
 
 
+def lowe_fixture():
+    kw = dict(n_scales=2, n_octaves=3, max_points=30000, profile=1, upsample=1)
+    pr = oracle.params(**kw)
+    img = sift_amd.synth_image(400, 300, seed=3, dense=True)
+    pts, meta, total = oracle.extract(pr, img, 400)
+    assert total == len(pts)
+    np.savez_compressed(os.path.join(HERE, "extract_lowe_400x300_up.npz"),
+                        image_sha256=hashlib.sha256(img.tobytes()).hexdigest(),
+                        points=oracle.sort_points(pts), quantized=oracle.quantize_descriptors(oracle.sort_points(pts)),
+                        n_scales=2, n_octaves=3, seed=3, dense=1)
+    print("lowe 400x300 up-sampled keypoints:", len(pts))
+
+
 def main():
+    if sys.argv[1:] == ["lowe"]:
+        lowe_fixture()
+        return
+    lowe_fixture()
     for S in (2, 3):
         pr = oracle.params(n_scales=S)
         blur, wnd, desc = oracle.tables(pr)

@@ -91,6 +91,34 @@ def test_real_image_crop_against_committed_golden(sift, oracle_mod):
     assert oracle_mod.sort_points(got.view(oracle_mod.POINT_DTYPE)).tobytes() == z["points"].tobytes()
 
 
+def test_lowe_against_committed_golden(sift, oracle_mod):
+    """Profile "lowe" with the doubled first octave against the committed fixture: refined
+    points and their 8-bit descriptors, byte for byte."""
+    import hashlib
+
+    z = np.load(os.path.join(GOLD, "extract_lowe_400x300_up.npz"))
+    sift.set_params(n_scales=int(z["n_scales"]), n_octaves=int(z["n_octaves"]), max_points=30000, profile=1, upsample=1)
+    img = sift.synth_image(400, 300, seed=int(z["seed"]), dense=bool(z["dense"]))
+    if hashlib.sha256(img.tobytes()).hexdigest() != str(z["image_sha256"]):
+        pytest.skip("libm differs from the machine that made the fixture: the synthetic image moved")
+    try:
+        pts, counts = sift.extract_batch(torch.from_numpy(img[None]).cuda(), 400)
+        n = int(counts[0])
+        q = sift.quantize_descriptors(pts, n).cpu().numpy()
+    finally:
+        sift.set_params()
+    got = sift.points_to_numpy(pts, n).view(oracle_mod.POINT_DTYPE)
+    assert oracle_mod.sort_points(got).tobytes() == z["points"].tobytes()
+    # descriptors quantised on the GPU, put into the fixture's order through the same sort
+    srt = oracle_mod.sort_points(got)
+    key = {r[["xpos", "ypos", "scale", "orientation"]].tobytes(): i for i, r in enumerate(srt)}
+    perm = np.array([key[r[["xpos", "ypos", "scale", "orientation"]].tobytes()] for r in got])
+    assert len(set(perm.tolist())) == n
+    out = np.empty_like(q)
+    out[perm] = q
+    assert np.array_equal(out, z["quantized"])
+
+
 def test_unaligned_pitch_and_odd_sizes(sift, oracle_mod):
     pr = _params(sift, oracle_mod, n_scales=2, n_octaves=3, max_points=20000)
     w, h, pitch = 301, 203, 303  # pitch not a multiple of 4: the scalar staging path

@@ -218,6 +218,21 @@ def test_extract_matches_committed_golden(oracle_mod, sift):
     assert oracle_mod.sort_points(pts).tobytes() == z["points"].tobytes()
 
 
+def test_lowe_extract_matches_committed_golden(oracle_mod, sift):
+    """Profile "lowe" with the doubled first octave: an anchor against the definition drifting
+    (oracle-generated; the reference has nothing to compare with)."""
+    z = np.load(os.path.join(GOLD, "extract_lowe_400x300_up.npz"))
+    pr = oracle_mod.params(n_scales=int(z["n_scales"]), n_octaves=int(z["n_octaves"]), max_points=30000,
+                           profile=1, upsample=1)
+    img = sift.synth_image(400, 300, seed=int(z["seed"]), dense=bool(z["dense"]))
+    if hashlib.sha256(img.tobytes()).hexdigest() != str(z["image_sha256"]):
+        pytest.skip("libm differs from the machine that made the fixture: the synthetic image moved")
+    pts, _, _ = oracle_mod.extract(pr, img, 400)
+    pts = oracle_mod.sort_points(pts)
+    assert pts.tobytes() == z["points"].tobytes()
+    assert np.array_equal(oracle_mod.quantize_descriptors(pts), z["quantized"])
+
+
 def test_real_image_crop_golden(oracle_mod):
     z = np.load(os.path.join(GOLD, "real_img1_crop.npz"))
     pr = oracle_mod.params(n_scales=int(z["n_scales"]), n_octaves=int(z["n_octaves"]), max_points=20000)
