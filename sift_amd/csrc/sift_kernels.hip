@@ -981,8 +981,8 @@ __device__ __forceinline__ bool edge_ok(const float *__restrict__ b, int p, floa
 
 constexpr int DET_THREADS = 512; // threads of a dense-detector block (a multiple of 32 dividing 1024)
 
-template <int S>
-__global__ __launch_bounds__(DET_THREADS) void detect_kernel(const float *__restrict__ arena, long arena_stride,
+template <int S, bool SCALE_MAJOR>
+__global__ __launch_bounds__(DET_THREADS, 4) void detect_kernel(const float *__restrict__ arena, long arena_stride,
                                                      unsigned *cand, long cand_stride,
                                                      unsigned *counts, long counts_stride,
                                                      const unsigned *gate, long gate_stride,
@@ -1022,6 +1022,153 @@ __global__ __launch_bounds__(DET_THREADS) void detect_kernel(const float *__rest
         if (c < CELLS) own |= 1u << it;
         if (j >= 0 && (j % XT_SDIMX) < XT_WRITTEN) taken |= 1u << it;
     }
+    // Scale i of the 96 x 32 block (bx, by) of octave oc, group g: val(it, t) is the value of
+    // blur plane i + t (t = 0..3) at this thread's tile cell `it`; b3 points at blur plane i.
+    auto eval = [&](const int g, const hl_octave &oc, const float *b3, const int bx, const int by,
+                    const unsigned inside, auto val) __attribute__((always_inline)) {
+        const int w = oc.w, h = oc.h, p = oc.p;
+        const long plane = (long)p * h;
+        __syncthreads(); // readers of the previous tiles are done
+        if (threadIdx.x == 0) hot_n = 0;
+        // The reference writes tile 0, then 1, then 2, and a later tile overwrites the
+        // tail of the one before.  Which write a cell keeps is known from its address:
+        // a cell of tile t survives unless tile t+1 writes the same address, so the
+        // three tiles go out together and only the surviving writes are made.
+#pragma unroll
+        for (int it = 0; it < ROUNDS; ++it) {
+            const int lin = cell_sx[it] + XT_SDIMX * cell_sy[it];
+            const bool in = (inside >> it) & 1u;
+            if ((own >> it) & 1u) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    if (t == 2 || !((taken >> it) & 1u))
+                        sh[t * XT_PLANE_OFF + lin] = in ? __fsub_rn(val(it, t), val(it, t + 1)) : 0.f;
+            }
+        }
+        __syncthreads();
+        // contrast test first: the survivors are listed, then shared out over the block
+        const int tx = threadIdx.x & 31;
+#pragma unroll
+        for (int pass = 0; pass < XT_BDIM * XT_BDIM / DET_THREADS; ++pass) {
+            const int ty = pass * (DET_THREADS / XT_BDIM) + (threadIdx.x >> 5);
+            const int y = XT_BDIM * by + ty;
+#pragma unroll
+            for (int tile = 0; tile < 3; tile += 2) {
+                const int x = XT_DATAX * bx + tx + XT_BDIM * tile;
+                const float pv = sh[XT_PLANE_OFF + 1 + tx + XT_BDIM * tile + XT_SDIMX * (1 + ty)];
+                const bool pass = x > 8 && x < w - 8 && y > 8 && y < h - 8 && fabsf(pv) > a.contrast;
+                const unsigned long long pm = __ballot(pass); // one LDS atomic per wave, not per pixel
+                if (pm) {
+                    unsigned base = 0;
+                    if (lane == 0) base = atomicAdd(&hot_n, (unsigned)__popcll(pm));
+                    base = __shfl(base, 0);
+                    if (pass)
+                        hot[base + __popcll(pm & ((1ull << lane) - 1ull))] =
+                            (unsigned)tx | ((unsigned)ty << 8) | ((unsigned)tile << 16);
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned n_hot = hot_n;
+        for (unsigned e0 = 0; e0 < n_hot; e0 += DET_THREADS) { // block-uniform trip count
+            const unsigned e = e0 + threadIdx.x;
+            bool hit = false;
+            unsigned xy = 0;
+            if (e < n_hot) {
+                const unsigned hv = hot[e];
+                const int htx = hv & 0xff, hty = (hv >> 8) & 0xff, tile = hv >> 16;
+                const int sy = 1 + hty;
+                int r = 0;
+                for (int tt = 0; tt <= tile; ++tt) { // the reference never resets its rank between tiles
+                    const int sx = 1 + htx + XT_BDIM * tt;
+                    const float cv = sh[XT_PLANE_OFF + sx + XT_SDIMX * sy];
+#pragma unroll
+                    for (int l = -1; l < 2; ++l)
+#pragma unroll
+                        for (int m = -1; m < 2; ++m)
+#pragma unroll
+                            for (int k = 0; k < 3; ++k)
+                                r += (cv >= sh[k * XT_PLANE_OFF + sx + l + XT_SDIMX * (sy + m)]) ? 1 : -1;
+                }
+                const int x = XT_DATAX * bx + htx + XT_BDIM * tile, y = XT_BDIM * by + hty;
+                xy = (unsigned)x | ((unsigned)y << 16);
+                hit = r == 9 && edge_ok(b3 + plane + x + (long)p * y, p, a.edge_limit);
+            }
+            // append, and announce the group once it holds `cap` points
+            const unsigned long long hm = __ballot(hit);
+            if (hm) {
+                const int leader = __ffsll((long long)hm) - 1;
+                const unsigned n_new = (unsigned)__popcll(hm);
+                unsigned base = 0;
+                if (lane == leader) {
+                    base = atomicAdd(&counts[g], n_new);
+                    if (base < (unsigned)a.cap && base + n_new >= (unsigned)a.cap)
+                        atomicMax(full, (unsigned)(HL_MAX_GROUPS - g));
+                }
+                base = __shfl(base, leader);
+                const unsigned idx = base + __popcll(hm & ((1ull << lane) - 1ull));
+                if (hit && idx < (unsigned)a.cap) cand[(long)g * a.cap + idx] = xy;
+            }
+        }
+    };
+    // which tile cells of the block (bx, by) are pixels of the image (bit it)
+    auto cells_inside = [&](const hl_octave &oc, const int bx, const int by) __attribute__((always_inline)) {
+        const int xb = XT_DATAX * bx - 1, yb = XT_BDIM * by - 1; // image position of tile cell (0, 0)
+        // a block whose tile lies inside the image needs no bounds tests (block-uniform)
+        if (xb >= 0 && xb + XT_WRITTEN <= oc.w && yb >= 0 && yb + 34 <= oc.h) return 0xffffffffu;
+        unsigned inside = 0;
+#pragma unroll
+        for (int it = 0; it < ROUNDS; ++it) {
+            const int x = xb + cell_sx[it], y = yb + cell_sy[it];
+            if (x >= 0 && x < oc.w && y >= 0 && y < oc.h) inside |= 1u << it;
+        }
+        return inside;
+    };
+    // The output keeps groups in order up to `cap` points and drops what follows
+    // (cudaSiftH.cu:12-13, 82).  A block that sees a group reach the cap announces
+    // it in a word of its own cache line; from then on that group and all later
+    // ones cannot change the output.  The word is read past the vector L1 together
+    // with the plane loads of a block.
+    auto first_full_group = [&]() __attribute__((always_inline)) {
+        const unsigned announced = __hip_atomic_load(full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return announced ? HL_MAX_GROUPS - (int)announced : HL_MAX_GROUPS; // every thread reads the same word
+    };
+    if constexpr (SCALE_MAJOR) {
+        // Group after group: all blocks work on one (octave, scale) at a time and load only
+        // its four planes.  With a small cap the first group usually fills it, and all the
+        // later ones (the other scales of the octave included) are never looked at; the price
+        // when no group fills the cap is that the planes shared by two scales are read twice.
+        for (int oi = 0; oi < a.n_oct; ++oi) {
+            const hl_octave oc = a.oct[oi];
+            const int p = oc.p;
+            const int xblocks = (oc.w + XT_DATAX - 1) / XT_DATAX;
+            const int n_units = a.dense0[oi + 1] - a.dense0[oi];
+            const long plane = (long)p * oc.h;
+            const float *blur = arena + z * arena_stride + oc.blur_off;
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                const int g = oi * S + i;
+                if (!((todo >> g) & 1u)) continue; // block-uniform
+                for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
+                    const int bx = u % xblocks, by = u / xblocks;
+                    const int full_from = first_full_group();
+                    const unsigned inside = cells_inside(oc, bx, by);
+                    const float *corner = blur + i * plane + (XT_DATAX * bx - 1) + (long)p * (XT_BDIM * by - 1);
+                    float v[ROUNDS][4];
+#pragma unroll
+                    for (int it = 0; it < ROUNDS; ++it) {
+                        const float *q = ((inside >> it) & 1u) ? corner + cell_sx[it] + p * cell_sy[it] : blur;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[it][k] = q[k * plane];
+                    }
+                    if (g >= full_from) return; // this group and all later ones are beyond the cap
+                    eval(g, oc, blur + i * plane, bx, by, inside, [&](int it, int t) { return v[it][t]; });
+                }
+            }
+        }
+    } else {
+    // Block after block, all scales of an octave at a time.  (The same steps as `eval`,
+    // written out: sharing the code costs this path 19 registers and a block per CU.)
     // dense0[] counts blocks of 96 x 32 pixels, octave after octave, row-major
     for (int unit = blockIdx.x; unit < a.dense0[a.n_oct]; unit += gridDim.x) {
         const int oi = find_octave(a.dense0, a.n_oct, unit);
@@ -1153,6 +1300,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_kernel(const float *__rest
                 }
             }
         }
+    }
     }
 }
 
@@ -2348,14 +2496,25 @@ int hl_detect(const float *arena, long arena_stride, unsigned *cand, long cand_s
     per_image = per_image < 32 ? 32 : (per_image > 1024 ? 1024 : per_image);
     if (gx > per_image) gx = per_image;
     dim3 grid(gx, 1, nimg), block(DET_THREADS);
+    // A cap of a few thousand points is normally reached inside the first group of an image
+    // dense enough to need this kernel: then the groups are taken one after the other and the
+    // work stops with the first (see the kernel); with a large cap every group is needed and
+    // the blocks are walked once, all scales of an octave at a time.
+    const int scale_major = gate && a->cap <= 4096; // (without a gate it is the whole detector, for sparse images too)
     hipStream_t s = (hipStream_t)stream;
     ScopedTimer t(2, s);
-    if (a->n_scales == 2)
-        hipLaunchKernelGGL((detect_kernel<2>), grid, block, 0, s, arena, arena_stride, cand, cand_stride,
-                           counts, counts_stride, gate, gate_stride, *a);
+#define DET_LAUNCH(SS, SM)                                                                          \
+    hipLaunchKernelGGL((detect_kernel<SS, SM>), grid, block, 0, s, arena, arena_stride, cand,       \
+                       cand_stride, counts, counts_stride, gate, gate_stride, *a)
+    if (a->n_scales == 2 && scale_major)
+        DET_LAUNCH(2, true);
+    else if (a->n_scales == 2)
+        DET_LAUNCH(2, false);
+    else if (scale_major)
+        DET_LAUNCH(3, true);
     else
-        hipLaunchKernelGGL((detect_kernel<3>), grid, block, 0, s, arena, arena_stride, cand, cand_stride,
-                           counts, counts_stride, gate, gate_stride, *a);
+        DET_LAUNCH(3, false);
+#undef DET_LAUNCH
     return launch_status();
 }
 

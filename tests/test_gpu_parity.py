@@ -249,10 +249,12 @@ def test_bad_arguments_are_reported_not_fatal(sift):
 
 
 @pytest.mark.parametrize("queue_cap", [0, 16, 300])
-def test_detection_paths_agree(sift, oracle_mod, queue_cap):
+@pytest.mark.parametrize("cap", [20000, 4000])
+def test_detection_paths_agree(sift, oracle_mod, queue_cap, cap):
     """Queue capacity 0 = dense detector only; tiny capacities force the overflow fall-back for
-    some (octave, scale) groups and not others.  All paths give the oracle's points."""
-    pr = _params(sift, oracle_mod, n_scales=2, n_octaves=4, max_points=20000)
+    some (octave, scale) groups and not others.  The fall-back walks the image block by block
+    (large cap) or group by group (cap 4000).  All paths give the oracle's points."""
+    pr = _params(sift, oracle_mod, n_scales=2, n_octaves=4, max_points=cap)
     w, h = 640, 480
     img = sift.synth_image(w, h, seed=6, dense=True)
     ref, meta, _ = oracle_mod.extract(pr, img, w)
