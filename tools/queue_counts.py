@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Candidates queued by the pyramid pass and keypoints accepted, per (octave, scale) group, for
+one sparse and one dense synthetic 1080p image under both profiles (sift_get_group_counts)."""
+import os
 import sys, numpy as np, torch
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sift_amd as sift
 from bench import gen_images
 for dense in (False, True):
