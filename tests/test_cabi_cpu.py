@@ -83,6 +83,29 @@ def test_text_writer_equals_oracle_writer(sift, oracle_mod):
     assert sift.format_points(pts) == oracle_mod.format_points(pts.view(oracle_mod.POINT_DTYPE))
 
 
+def test_fast_decimal_formatting_is_printf(sift, oracle_mod):
+    """The writer formats the 128 bins of a point with integer arithmetic; the bytes must be those
+    of printf("%.6f"), which the oracle's writer calls: exact ties (odd multiples of 2^-7 have seven
+    decimals ending in 5), values next to them, denormals, random bit patterns, and the values
+    that take the printf path (negative, 1000 and above, infinities, NaN)."""
+    rng = np.random.default_rng(8)
+    ties = np.arange(1, 4001, 2, dtype=np.float64) / 128.0  # up to 31.2
+    special = np.array([0.0, -0.0, 1.0, 0.2, 0.5, 0.9999995, 0.99999949, 999.9999, 999.99994, 1000.0, 123456.0,
+                        -0.25, 1e-45, 1e-38, 4.9999997e-7, 5.0000003e-7, 5e-7, 1.5e-6, 2.5e-6, np.inf, -np.inf,
+                        np.nan, 3.4e38, 16777216.0], dtype=np.float32)
+    near = np.concatenate([np.nextafter(ties.astype(np.float32), np.float32(0)),
+                           np.nextafter(ties.astype(np.float32), np.float32(1e9))])
+    bits_ = rng.integers(0, 2 ** 32, 40000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    small = rng.uniform(0, 1, 40000).astype(np.float32) * np.float32(10.0) ** rng.integers(-9, 3, 40000).astype(np.float32)
+    vals = np.concatenate([ties.astype(np.float32), special, near, bits_, small])
+    vals = np.concatenate([vals, np.zeros((-len(vals)) % 128, np.float32)])
+    pts = np.zeros(len(vals) // 128, sift.POINT_DTYPE)
+    pts["data"] = vals.reshape(-1, 128)
+    got = sift.format_points(pts)
+    want = oracle_mod.format_points(pts.view(oracle_mod.POINT_DTYPE))
+    assert got == want
+
+
 def test_pnm_loader_matches_gray_rule(sift, oracle_mod, tmp_path):
     rng = np.random.default_rng(4)
     rgb = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
