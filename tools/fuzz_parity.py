@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised GPU-against-oracle comparison: sizes, scales, octaves, thresholds, profiles,
-queue capacities, caps and image kinds drawn at random; every case must give the oracle's points
+queue capacities, caps, image kinds and entry points (single image, batch, 8-bit batch) drawn at
+random; every case must give the oracle's points
 bit for bit (or, over the cap, a subset of them of the cap's size).
 usage: tools/fuzz_parity.py [cases] [seed]"""
 import os
@@ -50,12 +51,28 @@ for case in range(cases):
         pr = oracle.params(**kw)
         ref, _, total = oracle.extract(pr, buf, w)
         sift.lib().sift_set_queue_cap(qcap)
-        d = torch.from_numpy(buf).cuda()
-        pts = sift.new_point_buffer()
-        sift.initDeviceVariables()
-        sift.extractSift(pts, d, w, pitch, h, None, 0, 0)
-        n = sift.getPointCount(0)
-        got = sift.points_to_numpy(pts, n).view(oracle.POINT_DTYPE)
+        route = int(rng.integers(0, 3))  # the single-image entry, the batch entry, the 8-bit batch entry
+        if route == 2 and kind == 3:
+            route = 1  # the 8-bit entry needs integer pixels
+        desc["route"] = route
+        if route == 0:
+            d = torch.from_numpy(buf).cuda()
+            pts = sift.new_point_buffer()
+            sift.initDeviceVariables()
+            sift.extractSift(pts, d, w, pitch, h, None, 0, 0)
+            n = sift.getPointCount(0)
+            got = sift.points_to_numpy(pts, n).view(oracle.POINT_DTYPE)
+        else:
+            # the image under test sits at a random place among copies of another image
+            nb = int(rng.integers(1, 4))
+            at = int(rng.integers(0, nb))
+            other = np.roll(buf, 5, axis=0)
+            stack = np.stack([buf if k == at else other for k in range(nb)])
+            if route == 2:
+                stack = stack.astype(np.uint8)
+            pts, counts = sift.extract_batch(torch.from_numpy(stack).cuda(), w)
+            n = int(counts[at])
+            got = sift.points_to_numpy(pts, n, offset=at * cap).view(oracle.POINT_DTYPE)
         if total <= cap:
             ok = len(got) == len(ref) and oracle.sort_points(got).tobytes() == oracle.sort_points(ref).tobytes()
         else:
