@@ -633,6 +633,19 @@ def test_parameter_validation(sift):
         sift.extract_batch(d, 48)
 
 
+def test_random_cases_slice():
+    """A slice of tools/fuzz_parity.py (random sizes, parameters, profiles, queue capacities, caps,
+    image kinds and entry points against the oracle), run as one separate process."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "80", "12345"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "80 cases, 0 bad" in r.stdout
+
+
 def test_command_line_front_end(sift, oracle_mod, tmp_path):
     """sift_cli <list file> <destination> (the counterpart of Sift/src/main.cc): run as a
     separate process, its text files equal the oracle's."""
