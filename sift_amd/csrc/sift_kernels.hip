@@ -992,6 +992,13 @@ __global__ __launch_bounds__(DET_THREADS, 4) void detect_kernel(const float *__r
     // pixels of the block that passed the contrast test: (tile << 16 | ty << 8 | tx)
     __shared__ unsigned hot[2 * XT_BDIM * XT_BDIM];
     __shared__ unsigned hot_n;
+    // The announcement word as thread 0 read it for the current block of pixels.  The
+    // word changes while the kernel runs; threads that read it themselves would see
+    // different values, skip different scales, and meet at different barriers.  Two
+    // slots, used in turn: a slot is rewritten only after every wave has passed the
+    // barrier that follows the read of the other one.
+    __shared__ unsigned s_announced[2];
+    unsigned turn = 0;
     const int lane = threadIdx.x & 63;
     const int z = blockIdx.z;
     cand += z * cand_stride;
@@ -1129,9 +1136,18 @@ __global__ __launch_bounds__(DET_THREADS, 4) void detect_kernel(const float *__r
     // it in a word of its own cache line; from then on that group and all later
     // ones cannot change the output.  The word is read past the vector L1 together
     // with the plane loads of a block.
-    auto first_full_group = [&]() __attribute__((always_inline)) {
-        const unsigned announced = __hip_atomic_load(full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return announced ? HL_MAX_GROUPS - (int)announced : HL_MAX_GROUPS; // every thread reads the same word
+    // thread 0 reads the word (before the plane loads are issued, so its latency passes
+    // with theirs) ...
+    auto read_announcement = [&]() __attribute__((always_inline)) {
+        return threadIdx.x == 0 ? __hip_atomic_load(full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    };
+    // ... and the block agrees on it: first group that is full, if any (block-uniform)
+    auto first_full_group = [&](const unsigned mine) __attribute__((always_inline)) {
+        if (threadIdx.x == 0) s_announced[turn] = mine;
+        __syncthreads();
+        const unsigned announced = s_announced[turn];
+        turn ^= 1u;
+        return announced ? HL_MAX_GROUPS - (int)announced : HL_MAX_GROUPS;
     };
     if constexpr (SCALE_MAJOR) {
         // Group after group: all blocks work on one (octave, scale) at a time and load only
@@ -1151,7 +1167,7 @@ __global__ __launch_bounds__(DET_THREADS, 4) void detect_kernel(const float *__r
                 if (!((todo >> g) & 1u)) continue; // block-uniform
                 for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
                     const int bx = u % xblocks, by = u / xblocks;
-                    const int full_from = first_full_group();
+                    const unsigned mine = read_announcement();
                     const unsigned inside = cells_inside(oc, bx, by);
                     const float *corner = blur + i * plane + (XT_DATAX * bx - 1) + (long)p * (XT_BDIM * by - 1);
                     float v[ROUNDS][4];
@@ -1161,6 +1177,7 @@ __global__ __launch_bounds__(DET_THREADS, 4) void detect_kernel(const float *__r
 #pragma unroll
                         for (int k = 0; k < 4; ++k) v[it][k] = q[k * plane];
                     }
+                    const int full_from = first_full_group(mine);
                     if (g >= full_from) return; // this group and all later ones are beyond the cap
                     eval(g, oc, blur + i * plane, bx, by, inside, [&](int it, int t) { return v[it][t]; });
                 }
@@ -1185,7 +1202,7 @@ __global__ __launch_bounds__(DET_THREADS, 4) void detect_kernel(const float *__r
         // it in a word of its own cache line; from then on that group and all later
         // ones cannot change the output.  The word is read past the vector L1 together
         // with the plane loads below.
-        const unsigned announced = __hip_atomic_load(full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned mine = read_announcement();
         // Every cell's S+3 blur values are requested before the first is used: one
         // memory round trip serves the tiles of all scales of the octave (the scales
         // share all but two of their planes).
@@ -1210,7 +1227,7 @@ __global__ __launch_bounds__(DET_THREADS, 4) void detect_kernel(const float *__r
             for (int k = 0; k < S + 3; ++k) v[it][k] = q[k * plane];
         }
         // first group that is full, if any (every thread read the same word: block-uniform)
-        const int full_from = announced ? HL_MAX_GROUPS - (int)announced : HL_MAX_GROUPS;
+        const int full_from = first_full_group(mine);
         if (oi * S >= full_from) return; // this octave and all later ones are beyond the cap
 #pragma unroll
         for (int i = 0; i < S; ++i) {

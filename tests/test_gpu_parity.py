@@ -175,6 +175,32 @@ def test_cap_overflow_keeps_a_subset_and_clamps_the_count(sift, oracle_mod, queu
         assert (got["scale"] == full["scale"][0]).sum() == first.sum()
 
 
+@pytest.mark.parametrize("queue_cap,cap", [(16, 60000), (65536, 60000), (0, 60000), (65536, 2500)])
+def test_cap_reached_while_the_dense_detector_runs(sift, oracle_mod, queue_cap, cap):
+    """A large image with a candidate nearly everywhere (contrast threshold 1, three scales):
+    several groups of the first octave reach the cap one after the other while thousands of
+    detector blocks are at work, and every block has to act on one consistent view of which
+    groups are full.  The output is cap points, all of them the oracle's."""
+    w, h = 2949, 1709
+    kw = dict(n_scales=3, n_octaves=4, extrema_thresh=1.0)
+    img = sift.synth_image(w, h, seed=196340271, dense=True)
+    every, _, total = oracle_mod.extract(oracle_mod.params(max_points=400000, **kw), img, w)
+    assert total == len(every) > 300000
+    have = {r.tobytes() for r in every}
+    sift.set_params(max_points=cap, **kw)
+    sift.lib().sift_set_queue_cap(queue_cap)
+    try:
+        for _ in range(3):  # the interleaving differs from run to run
+            got = _extract_gpu(sift, img, w).view(oracle_mod.POINT_DTYPE)
+            assert len(got) == cap
+            assert all(r.tobytes() in have for r in got)
+            assert len({r.tobytes() for r in got}) == cap
+    finally:
+        sift.lib().sift_set_queue_cap(65536)
+        sift.set_params()
+    sift.shutdown()
+
+
 def test_start_octave_argument(sift, oracle_mod):
     pr = _params(sift, oracle_mod, n_scales=2, n_octaves=4, max_points=20000)
     img = sift.synth_image(400, 300, seed=31, dense=True)

@@ -3,7 +3,7 @@
 queue capacities, caps, image kinds and entry points (single image, batch, 8-bit batch) drawn at
 random; every case must give the oracle's points
 bit for bit (or, over the cap, a subset of them of the cap's size).
-usage: tools/fuzz_parity.py [cases] [seed]"""
+usage: tools/fuzz_parity.py [cases] [seed] [max width] [max height]"""
 import os
 import sys
 import time
@@ -18,10 +18,12 @@ import sift_amd as sift  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+MAX_W = int(sys.argv[3]) if len(sys.argv) > 3 else 1300
+MAX_H = int(sys.argv[4]) if len(sys.argv) > 4 else 1000
 bad = 0
 t0 = time.time()
 for case in range(cases):
-    w, h = int(rng.integers(20, 1300)), int(rng.integers(20, 1000))
+    w, h = int(rng.integers(20, MAX_W)), int(rng.integers(20, MAX_H))
     S = int(rng.integers(2, 4))
     O = int(rng.integers(1, 6))
     profile = int(rng.integers(0, 2))
