@@ -1200,8 +1200,8 @@ __global__ __launch_bounds__(DET_THREADS, 4) void detect_kernel(const float *__r
         // The output keeps groups in order up to `cap` points and drops what follows
         // (cudaSiftH.cu:12-13, 82).  A block that sees a group reach the cap announces
         // it in a word of its own cache line; from then on that group and all later
-        // ones cannot change the output.  The word is read past the vector L1 together
-        // with the plane loads below.
+        // ones cannot change the output.  Thread 0 reads the word past the vector L1
+        // together with the plane loads below; the block agrees on it afterwards.
         const unsigned mine = read_announcement();
         // Every cell's S+3 blur values are requested before the first is used: one
         // memory round trip serves the tiles of all scales of the octave (the scales
@@ -1226,7 +1226,7 @@ __global__ __launch_bounds__(DET_THREADS, 4) void detect_kernel(const float *__r
 #pragma unroll
             for (int k = 0; k < S + 3; ++k) v[it][k] = q[k * plane];
         }
-        // first group that is full, if any (every thread read the same word: block-uniform)
+        // first group that is full, if any, as the whole block sees it
         const int full_from = first_full_group(mine);
         if (oi * S >= full_from) return; // this octave and all later ones are beyond the cap
 #pragma unroll
