@@ -394,7 +394,9 @@ def test_host_pipeline_writes_the_oracles_text_files(sift, oracle_mod, tmp_path)
     src.mkdir()
     dst.mkdir()
     paths, grays = [], []
-    for i, (w, h) in enumerate([(320, 200), (257, 131), (400, 300)]):
+    # seven files: sizes that grow and shrink from pair to pair (the pipeline keeps its buffers),
+    # an image too small for any keypoint, and an odd one left over at the end
+    for i, (w, h) in enumerate([(320, 200), (257, 131), (400, 300), (64, 48), (150, 333), (30, 20), (401, 299)]):
         img = sift.synth_image(w, h, seed=700 + i, dense=True).astype(np.uint8)
         if i == 2:  # a colour file: the loader's Q14 grey conversion is part of the pipeline
             rgb = np.stack([img, np.roll(img, 3, axis=1), np.roll(img, 5, axis=0)], axis=-1)
@@ -415,11 +417,11 @@ def test_host_pipeline_writes_the_oracles_text_files(sift, oracle_mod, tmp_path)
             sift.lib().sift_pipeline_drop_last_point(0)
         for p, g in zip(paths, grays):
             ref, _, total = oracle_mod.extract(pr, g, g.shape[1])
-            assert total == len(ref) > 10
+            assert total == len(ref) and (len(ref) > 10 or g.size < 10000)
             want = oracle_mod.format_points(ref).splitlines()
             got = open(dst / (os.path.basename(p) + ".sift.txt")).read().splitlines()
             if drop:  # the reference hands its writer count - 1 (sift.cu:125)
-                assert len(got) == len(want) - 1 and set(got) <= set(want)
+                assert len(got) == max(len(want) - 1, 0) and set(got) <= set(want)
             else:
                 assert sorted(got) == sorted(want)
 
