@@ -542,6 +542,34 @@ def test_full_size_1080p_three_scales(sift, oracle_mod):
     _assert_points_equal(oracle_mod, sift.points_to_numpy(d_pts, int(counts[0])), ref)
 
 
+def test_eight_slots_in_flight_with_changing_sizes(sift, oracle_mod):
+    """All eight stream slots busy at once, each on its own stream, and the image size of a slot
+    changes from round to round (its arena is re-planned while the other slots are in flight)."""
+    pr = _params(sift, oracle_mod, n_scales=2, n_octaves=3, max_points=2500)
+    sizes = [(200, 150), (333, 200), (97, 180), (400, 120), (64, 64)]
+    rng = np.random.default_rng(21)
+    cache = {}
+    for k, (w, h) in enumerate(sizes):
+        img = sift.synth_image(w, h, seed=40 + k, dense=True)
+        ref, _, total = oracle_mod.extract(pr, img, w)
+        assert total == len(ref)
+        cache[k] = (torch.from_numpy(img).cuda(), oracle_mod.sort_points(ref).tobytes(), len(ref))
+    streams = [torch.cuda.Stream() for _ in range(8)]
+    bufs = [sift.new_point_buffer() for _ in range(8)]
+    sift.initDeviceConstant()
+    for _ in range(10):
+        sift.initDeviceVariables()
+        pick = [int(rng.integers(0, len(sizes))) for _ in range(8)]
+        for slot in range(8):
+            w, h = sizes[pick[slot]]
+            sift.extractSift(bufs[slot], cache[pick[slot]][0], w, w, h, streams[slot], slot, 0)
+        for slot in range(8):
+            n = sift.getPointCount(slot)
+            assert n == cache[pick[slot]][2]
+            got = sift.points_to_numpy(bufs[slot], n).view(oracle_mod.POINT_DTYPE)
+            assert oracle_mod.sort_points(got).tobytes() == cache[pick[slot]][1]
+
+
 def test_two_host_threads_share_a_device(sift, oracle_mod):
     """Two host threads extract on one GPU at the same time, each on its own slot and stream
     (the library takes the device's lock per call); both get the oracle's points, many times."""
