@@ -66,8 +66,11 @@ for case in range(cases):
             got = sift.points_to_numpy(pts, n).view(oracle.POINT_DTYPE)
         else:
             # the image under test sits at a random place among copies of another image
-            nb = int(rng.integers(1, 4))
+            nb = int(rng.integers(1, 7))
             at = int(rng.integers(0, nb))
+            chunk = int(rng.choice([1, 2, 256]))  # launch sets of 1, 2 or all images, on two streams
+            desc["nb"], desc["at"], desc["chunk"] = nb, at, chunk
+            sift.lib().sift_set_batch_chunk(chunk)
             other = np.roll(buf, 5, axis=0)
             stack = np.stack([buf if k == at else other for k in range(nb)])
             if route == 2:
@@ -90,5 +93,6 @@ for case in range(cases):
     if case % 20 == 19:
         print(f"{case + 1} cases, {bad} bad, {time.time() - t0:.0f} s", flush=True)
 sift.lib().sift_set_queue_cap(65536)
+sift.lib().sift_set_batch_chunk(256)
 print("done:", cases, "cases,", bad, "bad")
 sys.exit(1 if bad else 0)
