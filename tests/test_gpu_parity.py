@@ -40,6 +40,26 @@ def test_pyramid_stages_bit_exact(sift, oracle_mod, w, h, S):
     _assert_planes_equal(sift.computeGradient(blur, w), oracle_mod.gradient(pr, ref_blur, w), w, "gradient")
 
 
+def test_pyramid_stages_on_random_shapes(sift, oracle_mod):
+    """The stage entries (blurOctave, computeDiffOfGauss, computeHessian, computeGradient) on
+    random sizes and pitches (any multiple of 4 floats), bit for bit."""
+    rng = np.random.default_rng(31)
+    for case in range(12):
+        w, h, S = int(rng.integers(8, 900)), int(rng.integers(8, 500)), int(rng.integers(2, 4))
+        pitch = (w + 3) // 4 * 4 + 4 * int(rng.integers(0, 20))
+        pr = _params(sift, oracle_mod, n_scales=S)
+        img = sift.synth_image(w, h, seed=900 + case, pitch=pitch, dense=bool(case & 1))
+        host = oracle_mod.pitched(img[:, :w], pitch)
+        blur = sift.blurOctave(torch.from_numpy(host).cuda(), w)
+        ref_blur = oracle_mod.yblur(pr, oracle_mod.xblur(pr, host, w), w)
+        what = f"case {case}: {w}x{h} pitch {pitch} S={S} "
+        _assert_planes_equal(blur, ref_blur, w, what + "blur")
+        _assert_planes_equal(sift.computeDiffOfGauss(blur, w), oracle_mod.dog(pr, ref_blur, w), w, what + "DoG")
+        _assert_planes_equal(sift.computeHessian(blur, w), oracle_mod.hessian(pr, ref_blur, w), w, what + "Hessian")
+        _assert_planes_equal(sift.computeGradient(blur, w), oracle_mod.gradient(pr, ref_blur, w), w, what + "gradient")
+    sift.set_params()
+
+
 def _extract_gpu(sift, img_host, w):
     h, pitch = img_host.shape
     d_img = torch.from_numpy(np.nan_to_num(img_host, nan=-1e30)).cuda()
