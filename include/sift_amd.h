@@ -153,6 +153,17 @@ void sift_set_queue_cap(int n);
  * queue's capacity marks a group the dense detector redid).  Returns the number
  * of groups written (at most n), or -1.  No counterpart in the reference. */
 int sift_get_group_counts(int streamIdx, unsigned *accepted, unsigned *queued, int n);
+/* Diagnostics: the S+3 blur planes the pyramid pass left in the scratch arena for
+ * one image and octave (what blurOctave's x and y passes produce, cudaSiftH.cu:210-259;
+ * for octave o > 0 the source was resizeKernel's even pixels of plane S of octave o-1,
+ * cudaSiftD.cu:544-559), copied to host memory after the slot's work has completed.
+ * slot: 0..SIFT_MAX_SLOTS-1 = the stream slots of extractSift, SIFT_MAX_SLOTS + l = launch
+ * lane l of the batch entries (a batch of at most one launch set leaves image i of the
+ * batch at image i of lane 0).  octave counts from the first octave processed.  Plane k
+ * starts at h_dst + k*pitch*height; columns [width, pitch) hold don't-care values.
+ * h_dst NULL: only the geometry is returned.  Returns 0 or -1. */
+int sift_debug_read_planes(int slot, int image, int octave, float *h_dst, long dst_floats,
+                           int *width, int *pitch, int *height);
 /* launch sets in flight at once, each on a private stream and arena: 1 or 2
  * (default 2: the short kernels of the small octaves of one set overlap the
  * long kernels of the other) */

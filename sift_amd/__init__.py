@@ -74,6 +74,7 @@ SYMBOLS = {
     "sift_set_batch_lanes": (None, [C.c_int]),
     "sift_set_queue_cap": (None, [C.c_int]),
     "sift_get_group_counts": (C.c_int, [C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.c_int]),
+    "sift_debug_read_planes": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, C.c_long, _ip, _ip, _ip]),
     "sift_device_count": (C.c_int, []),
     "sift_set_device": (C.c_int, [C.c_int]),
     "sift_dev_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
@@ -249,6 +250,18 @@ def group_counts(streamIdx=0):
         _check()
         raise SiftError("sift_get_group_counts failed")
     return list(a[:n]), list(q[:n])
+
+
+def debug_read_planes(slot, image, octave):
+    """The S+3 blur planes the pyramid pass left in the arena of `slot` (0..7 = extractSift's
+    stream slots, 8 + l = batch lane l) for one image and octave: (planes (S+3, h, pitch), width)."""
+    w, p, h = C.c_int(), C.c_int(), C.c_int()
+    _ok(lib().sift_debug_read_planes(slot, image, octave, None, 0, C.byref(w), C.byref(p), C.byref(h)))
+    n = get_params().n_scales + 3
+    out = np.empty((n, h.value, p.value), np.float32)
+    _ok(lib().sift_debug_read_planes(slot, image, octave, out.ctypes.data_as(_fp), out.size, C.byref(w),
+                                     C.byref(p), C.byref(h)))
+    return out, w.value
 
 
 def getPointCount(streamIdx=0):

@@ -83,6 +83,7 @@ int hl_device_sync(void);
 int hl_event_create(void **e);
 int hl_event_destroy(void *e);
 int hl_event_record(void *e, void *stream);
+int hl_event_sync(void *e);
 int hl_stream_wait_event(void *stream, void *e);
 int hl_host_alloc(void **p, size_t bytes);
 int hl_host_free(void *p);

@@ -43,7 +43,11 @@ typedef struct {
     unsigned *cand;   /* nimg * groups * cap */
     long cand_stride;
     unsigned *queue;  /* nimg * queue_stride: contrast candidates per octave and scale */
-    void *last_stream;
+    /* Library-owned event recorded behind the slot's latest work.  The caller's stream
+     * handle is never kept: the reference's caller creates its streams per image pair and
+     * destroys them afterwards (sift.cu:96,130), so a stored handle would dangle. */
+    void *done;
+    int busy; /* done has been recorded and not yet waited for */
 } slot_ctx;
 
 /* g_mu guards the parameters and tables; g_dev_mu[d] guards device d's slots, batch
@@ -249,7 +253,25 @@ static void free_slot(slot_ctx *c)
     if (c->cand) hl_free(c->cand);
     if (c->queue) hl_free(c->queue);
     if (c->sub) hl_free(c->sub);
+    if (c->done) hl_event_destroy(c->done);
     memset(c, 0, sizeof *c);
+}
+
+/* Waits for the slot's latest work.  A failure here means the device lost that work:
+ * the slot is torn down so that the next call plans it afresh instead of meeting the
+ * same error for ever. */
+static int drain_slot(slot_ctx *c, const char *who)
+{
+    if (!c->valid || !c->busy)
+        return 0;
+    int r = hl_event_sync(c->done);
+    c->busy = 0;
+    if (r) {
+        fail_hl(r, who);
+        hl_device_sync();
+        free_slot(c);
+    }
+    return r;
 }
 
 void sift_shutdown(void)
@@ -309,10 +331,8 @@ static int ensure_arena(slot_ctx *c, int w, int h, int oct0, int nimg)
         c->cap == cap && c->nimg >= nimg && c->queue_cap == g_queue_cap &&
         c->profile == g_params.profile && c->upsample == up)
         return 0;
-    if (c->valid) { /* geometry changed: drain the slot before its memory goes away */
-        int r = hl_stream_sync(c->last_stream);
-        if (r) return fail_hl(r, "draining slot");
-    }
+    if (c->valid && drain_slot(c, "draining slot")) /* geometry changed: its memory goes away */
+        return -1;
     free_slot(c);
 
     long off = 0, qoff = 0;
@@ -368,6 +388,8 @@ static int ensure_arena(slot_ctx *c, int w, int h, int oct0, int nimg)
     c->cap = cap;
     c->nimg = nimg;
     c->queue_cap = g_queue_cap;
+    r = hl_event_create(&c->done);
+    if (r) return fail_hl(r, "creating slot event");
     c->valid = 1;
     return 0;
 }
@@ -484,7 +506,9 @@ static int enqueue_extract(slot_ctx *c, SiftPoint *pts, unsigned char *meta, con
     if (r) return fail_hl(r, "keypoint kernel");
     r = hl_finalize_counts(base_count, c->counts, COUNT_WORDS, ka.n_groups, cap, nimg, stream);
     if (r) return fail_hl(r, "count update");
-    c->last_stream = stream;
+    r = hl_event_record(c->done, stream);
+    if (r) return fail_hl(r, "recording slot event");
+    c->busy = 1;
     return 0;
 }
 
@@ -560,10 +584,11 @@ int getPointCount(int streamIdx)
         if (ensure_slot_counter(dev))
             break;
         slot_ctx *c = &g_slots[dev][streamIdx];
+        if (drain_slot(c, "getPointCount"))
+            break;
         int r = 0;
-        if (c->valid) r = hl_stream_sync(c->last_stream);
         unsigned v = 0;
-        if (!r) r = hl_memcpy_async(&v, g_slot_counter[dev] + streamIdx, sizeof v, 2, NULL);
+        r = hl_memcpy_async(&v, g_slot_counter[dev] + streamIdx, sizeof v, 2, NULL);
         if (!r) r = hl_stream_sync(NULL);
         if (r) {
             fail_hl(r, "getPointCount");
@@ -589,8 +614,12 @@ int sift_get_group_counts(int streamIdx, unsigned *accepted, unsigned *queued, i
         set_err("sift_get_group_counts: slot %d has not been used", streamIdx);
     } else {
         unsigned words[COUNT_WORDS];
-        int r = hl_stream_sync(c->last_stream);
-        if (!r) r = hl_memcpy_async(words, c->counts, sizeof words, 2, NULL);
+        int r = drain_slot(c, "sift_get_group_counts");
+        if (r) {
+            unlock_device(dev);
+            return -1;
+        }
+        r = hl_memcpy_async(words, c->counts, sizeof words, 2, NULL);
         if (!r) r = hl_stream_sync(NULL);
         if (r) {
             fail_hl(r, "sift_get_group_counts");
@@ -605,6 +634,49 @@ int sift_get_group_counts(int streamIdx, unsigned *accepted, unsigned *queued, i
     }
     unlock_device(dev);
     return result;
+}
+
+int sift_debug_read_planes(int slot, int image, int octave, float *h_dst, long dst_floats, int *width,
+                           int *pitch, int *height)
+{
+    if (slot < 0 || slot >= SIFT_MAX_SLOTS + N_LANES || image < 0 || octave < 0) {
+        set_err("sift_debug_read_planes: bad arguments");
+        return -1;
+    }
+    const int dev = lock_device("sift_debug_read_planes");
+    if (dev < 0) return -1;
+    int rc = -1;
+    slot_ctx *c = &g_slots[dev][slot];
+    do {
+        if (!c->valid || image >= c->nimg || octave >= c->n_oct) {
+            set_err("sift_debug_read_planes: slot %d holds no image %d / octave %d", slot, image, octave);
+            break;
+        }
+        if (drain_slot(c, "sift_debug_read_planes"))
+            break;
+        const long n = (long)c->op[octave] * c->oh[octave] * (c->S + 3);
+        if (width) *width = c->ow[octave];
+        if (pitch) *pitch = c->op[octave];
+        if (height) *height = c->oh[octave];
+        if (!h_dst) { /* geometry query */
+            rc = 0;
+            break;
+        }
+        if (dst_floats < n) {
+            set_err("sift_debug_read_planes: destination holds %ld floats, %ld needed", dst_floats, n);
+            break;
+        }
+        int r = hl_memcpy_async(h_dst, c->arena + (long)image * c->arena_stride + c->blur_off[octave],
+                                sizeof(float) * (size_t)n, 2, NULL);
+        if (!r) r = hl_stream_sync(NULL);
+        if (r) {
+            fail_hl(r, "sift_debug_read_planes");
+            break;
+        }
+        rc = 0;
+    } while (0);
+    unlock_device(dev);
+    return rc;
 }
 
 /* ---- batch ------------------------------------------------------------------ */

@@ -2307,6 +2307,7 @@ int hl_event_create(void **e)
 }
 int hl_event_destroy(void *e) { return chk(hipEventDestroy((hipEvent_t)e)); }
 int hl_event_record(void *e, void *stream) { return chk(hipEventRecord((hipEvent_t)e, (hipStream_t)stream)); }
+int hl_event_sync(void *e) { return chk(hipEventSynchronize((hipEvent_t)e)); }
 int hl_stream_wait_event(void *stream, void *e)
 {
     return chk(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)e, 0));

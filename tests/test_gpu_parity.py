@@ -750,3 +750,37 @@ def test_command_line_front_end(sift, oracle_mod, tmp_path):
         assert sorted(got) == sorted(oracle_mod.format_points(ref).splitlines())
     r = subprocess.run([exe, str(tmp_path / "missing.txt"), str(dst)], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "Unable to open file" in r.stderr
+
+
+def test_slot_outlives_the_callers_stream(sift, oracle_mod):
+    """The reference's caller creates a stream per image and destroys it after the read-back
+    (Sift/src/sift.cu:96,130).  The slot must not hold on to it: the next image on the same slot
+    has another size (the arena is planned afresh, which waits for the old work) and another
+    stream, and getPointCount follows a stream that no longer exists either."""
+    import ctypes as C
+
+    pr = _params(sift, oracle_mod, n_scales=2, n_octaves=3, max_points=20000)
+    L = sift.lib()
+    slot = 5
+    sift.initDeviceVariables()
+    total = 0
+    for k, (w, h) in enumerate([(256, 192), (320, 200), (200, 264)]):
+        img = sift.synth_image(w, h, seed=40 + k, dense=True)
+        ref, _, _ = oracle_mod.extract(pr, img, w)
+        d = torch.from_numpy(img).cuda()
+        pts = sift.new_point_buffer()
+        torch.cuda.synchronize()
+        s = C.c_void_p()
+        assert L.sift_stream_create(C.byref(s)) == 0
+        if k:  # appends behind the earlier images' count: start this image's list at zero
+            sift.initDeviceVariables()
+        L.extractSift(C.c_void_p(pts.data_ptr()), C.c_void_p(d.data_ptr()), w, w, h, s, slot, 0)
+        assert sift.last_error() == ""
+        assert L.sift_stream_sync(s) == 0
+        assert L.sift_stream_destroy(s) == 0
+        n = sift.getPointCount(slot)
+        assert n == len(ref) > 0
+        _assert_points_equal(oracle_mod, sift.points_to_numpy(pts, n), ref)
+        total += n
+    acc, _ = sift.group_counts(slot)
+    assert sum(acc) == n
