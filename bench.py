@@ -8,6 +8,11 @@ per GPU) every rank owns its own batch: images are independent, there is no
 collective on the data path, so scaling is weak and `value` is the sum over
 ranks divided by the slowest rank's time.
 
+`--mode config4` is BASELINE.json's configs[3]: 4096 images (seeds 1000..5095), image i
+on rank i mod N, every rank's share resident in its HBM and worked through in batches of
+256; `value` is 4096 divided by the slowest rank's time (strong scaling) and rank 0
+gathers the per-image keypoint counts in image order.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -42,19 +47,42 @@ def algorithmic_bytes(s):
     `pyramid`: what the fused row+column kernel has to move: read the octave's
     source once, write the S+3 blur planes (DoG values are formed by their
     readers; the next octave reads blur plane S in place).
-    `two_pass`: the same work as a separable two-pass design with stored DoG
-    planes and a materialised next-octave base: row pass R 1 + W (S+3), column
-    pass R (S+3) + W S + W (S+2), down-sample R 1/4 + W 1/4; kept for comparison.
-    `two_pass_and_extrema`: the two-pass figure plus the detector's read of the
-    S+2 DoG planes (86 B/px at S = 2): the bytes a conventional layout of this
-    path moves; reported beside the headline figure, never as it.
     `detect`: the dense detector reads the S+3 blur planes."""
-    return {
-        "pyramid": (1 + (s + 3)) * 4.0,
-        "two_pass": (4 * s + 9.5) * 4.0,
-        "two_pass_and_extrema": (5 * s + 11.5) * 4.0,
-        "detect": (s + 3) * 4.0,
-    }
+    return {"pyramid": (1 + (s + 3)) * 4.0, "detect": (s + 3) * 4.0}
+
+
+def host_threads():
+    """Threads for host-side work: the CPUs this process may run on, within the share the
+    job was given (OMP_NUM_THREADS carries it on the GPU boxes)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        share = int(os.environ.get("OMP_NUM_THREADS", "0"))
+    except ValueError:
+        share = 0
+    return max(1, min(n, share) if share > 0 else n)
+
+
+def photo_density_rate(sift_amd, torch, steps=3, n=64):
+    """Images/s on images with the keypoint density of a photograph: the committed 320x256 crop
+    of the reference's Sift/img/img1.ppm, mirrored and tiled to 1920x1080 (about 11 k keypoints
+    per image before the cap of 2500)."""
+    path = os.path.join(ROOT, "tests", "golden", "real_img1_crop.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)["gray"].astype(np.float32)
+    row = np.concatenate([g, g[:, ::-1]] * 3, axis=1)
+    img = np.ascontiguousarray(np.concatenate([row, row[::-1]] * 3, axis=0)[:H, :W])
+    batch = torch.from_numpy(np.stack([np.roll(img, 7 * i, axis=1) for i in range(n)])).cuda()
+    d_pts = torch.empty((n * CAP, sift_amd.POINT_FLOATS), dtype=torch.float32, device="cuda")
+    _, counts = sift_amd.extract_batch(batch, W, d_pts=d_pts)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        _, counts = sift_amd.extract_batch(batch, W, d_pts=d_pts)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"images_per_s": n * steps / dt, "keypoints_per_image": float(counts.mean()), "images": n,
+            "source": "crop of Sift/img/img1.ppm tiled to 1920x1080 (tests/golden/real_img1_crop.npz)"}
 
 
 def gen_images(n, seed0, dense, threads):
@@ -129,6 +157,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--chunk", type=int, default=0, help="images per launch set (0 = library default)")
     ap.add_argument("--lanes", type=int, default=0, help="launch sets in flight (0 = library default)")
+    ap.add_argument("--strip-rows", type=int, default=0, help="rows per strip of the pyramid pass (0 = chosen per launch)")
     ap.add_argument("--dense", action="store_true", help="high keypoint density images")
     ap.add_argument("--queue-cap", type=int, default=-1,
                     help="candidate queue entries per image and scale (0 = dense detector only; -1 = library default)")
@@ -140,8 +169,14 @@ def main():
     ap.add_argument("--profile", choices=["ref", "lowe"], default="ref",
                     help="semantics profile (ref = the headline configuration)")
     ap.add_argument("--upsample", action="store_true", help="profile lowe: doubled first octave")
+    ap.add_argument("--mode", choices=["config3", "config4"], default="config3",
+                    help="config3: every rank its own batch (weak scaling, the headline); config4: 4096 images "
+                         "dealt over the ranks, image i on rank i mod N (strong scaling)")
+    ap.add_argument("--images", type=int, default=4096, help="config4: images in the whole job")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the device-copy ceiling measurement")
+    ap.add_argument("--no-photo", action="store_true", help="skip the photograph-density extra")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=48)
+    ap.add_argument("--cpu-sample", type=int, default=256)
     args = ap.parse_args()
     S = args.scales
 
@@ -181,13 +216,29 @@ def main():
         sift_amd.lib().sift_set_batch_chunk(args.chunk)
     if args.lanes:
         sift_amd.lib().sift_set_batch_lanes(args.lanes)
+    if args.strip_rows:
+        sift_amd.lib().sift_set_strip_rows(args.strip_rows)
     if args.queue_cap >= 0:
         sift_amd.lib().sift_set_queue_cap(args.queue_cap)
 
-    threads = min(16, os.cpu_count() or 1)
-    host = gen_images(args.batch, SEED0 + rank * args.batch, args.dense, threads)
+    threads = host_threads()
+    config4 = args.mode == "config4"
+    if config4:
+        # image i of the job lives on rank i mod world; all of a rank's images are resident
+        mine = list(range(rank, args.images, world))
+        n_local = len(mine)
+        host = np.empty((n_local, H, W), np.float32)
+
+        def one(k):
+            sift_amd.lib().sift_synth_image(host[k].ctypes.data, W, W, H, SEED0 + mine[k], int(args.dense))
+
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(one, range(n_local)))
+    else:
+        n_local = args.batch
+        host = gen_images(args.batch, SEED0 + rank * args.batch, args.dense, threads)
     d_imgs = torch.from_numpy(host.astype(np.uint8) if args.u8 else host).cuda()  # the images hold integers
-    d_pts = torch.empty((args.batch * CAP, sift_amd.POINT_FLOATS), dtype=torch.float32, device="cuda")
+    d_pts = torch.empty((n_local * CAP, sift_amd.POINT_FLOATS), dtype=torch.float32, device="cuda")
 
     def barrier():
         torch.cuda.synchronize()
@@ -195,19 +246,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def step():
+        """One pass of the hot path over this rank's images, a batch at a time."""
+        got = []
+        for lo in range(0, n_local, args.batch):
+            hi = min(n_local, lo + args.batch)
+            _, c = sift_amd.extract_batch(d_imgs[lo:hi], W, d_pts=d_pts[lo * CAP:hi * CAP])
+            got.append(c)
+        return np.concatenate(got)
+
     counts = None
     for _ in range(args.warmup):
-        _, counts = sift_amd.extract_batch(d_imgs, W, d_pts=d_pts)
+        counts = step()
 
     sift_amd.timing_reset()
     sift_amd.timing_enable(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        _, counts = sift_amd.extract_batch(d_imgs, W, d_pts=d_pts)
+        counts = step()
     barrier()
     elapsed = time.perf_counter() - t0
     sift_amd.timing_enable(False)
+    all_counts = None
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -215,11 +276,18 @@ def main():
         k = torch.tensor([float(counts.sum())], dtype=torch.float64)
         dist.all_reduce(k, op=dist.ReduceOp.SUM)
         keypoints_per_step = float(k.item())
+        if config4:  # the final host-side gather, in image order
+            parts = [None] * world
+            dist.all_gather_object(parts, counts.tolist())
+            all_counts = np.zeros(args.images, np.int64)
+            for r, part in enumerate(parts):
+                all_counts[r::world] = part
     else:
         keypoints_per_step = float(counts.sum())
+        all_counts = counts if config4 else None
 
-    images = args.batch * args.steps * world
-    value = images / elapsed
+    images_per_step = args.images if config4 else args.batch * world
+    value = images_per_step * args.steps / elapsed
 
     out = {
         "metric": "images/sec at 1080p (keypoints + 128-D descriptors, whole job)",
@@ -230,20 +298,27 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if config4 else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.batch} synthetic {W}x{H} {'u8' if args.u8 else 'f32'} images per GPU, {S} scales, {O} octaves, "
+            "workload": (f"{args.images} synthetic {W}x{H} {'u8' if args.u8 else 'f32'} images in the whole job (seeds "
+                         f"{SEED0}..{SEED0 + args.images - 1}), image i on GPU i mod {world}, batches of {args.batch}, "
+                         if config4 else
+                         f"{args.batch} synthetic {W}x{H} {'u8' if args.u8 else 'f32'} images per GPU, ")
+                        + f"{S} scales, {O} octaves, "
                         f"cap {CAP}, semantics profile {args.profile}{' with doubled first octave' if args.upsample else ''}, "
                         f"inputs resident in HBM"
                         + (", dense blobs" if args.dense else ""),
-            "parallelism": f"dp{world} (independent image batches, no collective)",
+            "parallelism": f"dp{world} (independent images, no collective; host-side gather of the results)",
         },
         "keypoints_per_s": keypoints_per_step * args.steps / elapsed,
-        "keypoints_per_image": keypoints_per_step / (args.batch * world),
+        "keypoints_per_image": keypoints_per_step / images_per_step,
     }
+    if config4 and all_counts is not None:
+        out["gathered_counts"] = {"images": int(len(all_counts)), "keypoints": int(all_counts.sum()),
+                                  "checksum": int((all_counts * (np.arange(len(all_counts)) % 251 + 1)).sum())}
 
     if rank == 0:
         ab = algorithmic_bytes(S)
@@ -258,7 +333,7 @@ def main():
         # dominant kernel = the one with the most device time
         dom = max(kernel_names, key=lambda k: kern[k]["ms_total"])
         dom_ms, dom_n = kern[dom]["ms_total"], max(kern[dom]["launches"], 1)
-        bytes_total = ab[dom] * px * args.batch * args.steps  # this rank
+        bytes_total = ab[dom] * px * n_local * args.steps  # this rank
         achieved = bytes_total / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
         out["roofline"] = {
             "bound": "hbm",
@@ -275,41 +350,31 @@ def main():
             "timing": "HIP events around every launch, on the launch stream, inside the timed region",
         }
         if dom == "pyramid":
-            out["roofline"]["two_pass_equivalent_GBps"] = achieved / 1e9 * ab["two_pass"] / ab["pyramid"]
-            # the same kernel time priced with the bytes of a two-pass layout with stored DoG
-            # planes and a detector that reads them; exceeds the HBM peak because this
-            # design never moves those bytes
-            out["roofline"]["conventional_layout"] = {
-                "bytes_per_px": ab["two_pass_and_extrema"],
-                "equivalent_GBps": achieved / 1e9 * ab["two_pass_and_extrema"] / ab["pyramid"],
-                "equivalent_frac": achieved / HBM_PEAK * ab["two_pass_and_extrema"] / ab["pyramid"],
-            }
-            out["roofline"]["note"] = ("fused row+column pass: 24 B/px moved (a two-pass design with stored DoG "
-                                       "planes moves 70 B/px) beside 190 FP32 FMA/px")
-        out["kernels_ms_per_image"] = {k: v["ms_total"] / (args.batch * args.steps) for k, v in kern.items()}
+            out["roofline"]["note"] = ("fused row + column pass: reads the octave's source once and writes the S+3 "
+                                       "blur planes, 24 B/px at 2 scales, beside 190 FP32 FMA per pixel")
+            # the same kernel against the FP32 vector issue rate (157.3 TFLOP/s data sheet, 2 flops per FMA)
+            fma = 38.0 * (S + 3) * px * n_local * args.steps
+            out["roofline"]["fp32_issue_frac"] = 2.0 * fma / (dom_ms * 1e-3) / 157.3e12
+        out["kernels_ms_per_image"] = {k: v["ms_total"] / (n_local * args.steps) for k, v in kern.items()}
         # HBM-side bytes per launch of the dominant kernel from rocprofv3 counters (separate
         # FETCH_SIZE / WRITE_SIZE passes over this same command, tools/prof_pmc.sh), if committed
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tf):
             try:
                 t = json.load(open(tf)).get(kernel_names[dom])
-                if t and t.get("batch") == args.batch:
+                if t and t.get("batch") == args.batch and not config4:
                     out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = ("rocprofv3 FETCH_SIZE (x2) and WRITE_SIZE passes over this "
+                                                         "command, profiles/pmc_traffic.json")
             except (ValueError, OSError):
                 pass
-        # the same kernels without the second launch set competing for the chip
-        if world == 1:
-            sift_amd.lib().sift_set_batch_lanes(1)
-            sift_amd.timing_reset()
-            sift_amd.timing_enable(True)
-            sift_amd.extract_batch(d_imgs, W, d_pts=d_pts)
-            sift_amd.timing_enable(False)
-            ms1, n1 = sift_amd.timing_read(names[dom])
-            if ms1 > 0:
-                a1 = ab[dom] * px * args.batch / (ms1 * 1e-3)
-                out["roofline_single_stream"] = {"kernel": kernel_names[dom], "achieved": a1 / 1e9,
-                                                 "frac": a1 / HBM_PEAK, "avg_launch_ms": ms1 / max(n1, 1)}
-            sift_amd.lib().sift_set_batch_lanes(args.lanes or 2)
+        # what this GPU's memory system gives a kernel that only moves bytes, measured in this run
+        if not args.no_ceiling:
+            ceil_gbps = sift_amd.measure_copy_ceiling(2 << 30, 5)
+            out["roofline"]["copy_ceiling_GBps"] = ceil_gbps
+            out["roofline"]["frac_of_copy_ceiling"] = achieved / 1e9 / ceil_gbps if ceil_gbps > 0 else None
+        if world == 1 and not args.no_photo and not config4 and profile == 0 and S == 2 and not args.upsample:
+            out["photo_density"] = photo_density_rate(sift_amd, torch)
         if world == 1 and args.host_fed:
             out["host_fed"] = host_fed_rates(sift_amd, torch, host, d_pts, args.steps)
         if world == 1 and not args.no_cpu_baseline:
@@ -318,16 +383,25 @@ def main():
             pr = oracle.params(n_octaves=O, n_scales=S, max_points=CAP, profile=profile, upsample=int(args.upsample))
             n_cpu = min(args.cpu_sample, args.batch)
             t0 = time.perf_counter()
-            _, cpu_counts = oracle.extract_batch(pr, host[:n_cpu], W, n_threads=threads)
+            cpu_pts, cpu_counts = oracle.extract_batch(pr, host[:n_cpu], W, n_threads=threads)
             dt = time.perf_counter() - t0
+            # the GPU's points of the same images, as sorted bytes (the append order is an atomic's)
+            same = bool(np.array_equal(cpu_counts, counts[:n_cpu]))
+            for i in range(n_cpu):
+                if not same:
+                    break
+                g = sift_amd.points_to_numpy(d_pts, int(counts[i]), offset=i * CAP).view(oracle.POINT_DTYPE)
+                same = oracle.sort_points(g).tobytes() == oracle.sort_points(cpu_pts[i][:cpu_counts[i]]).tobytes()
             out["cpu_baseline"] = {
                 "value": n_cpu / dt,
                 "unit": "images/s",
                 "cores": threads,
+                "host_cpus": os.cpu_count(),
                 "kind": "port",
                 "sample": f"first {n_cpu} images of the same batch, C restatement of the reference "
                           f"kernels, one image per thread",
-                "keypoints_match_gpu": bool(np.array_equal(cpu_counts, counts[:n_cpu])),
+                "keypoints_match_gpu": same,
+                "match": "sorted point records of every sampled image, byte for byte",
             }
         print(json.dumps(out))
     if dist is not None:

@@ -138,7 +138,7 @@ int sift_extract_batch_async(SiftPoint *d_pts, unsigned char *d_meta, unsigned *
  * min(255, round(512 * d_pts[j].data[k])) for the first n points.  Asynchronous
  * on `stream`.  Returns 0 or a negative error. */
 int sift_quantize_descriptors(const SiftPoint *d_pts, int n, unsigned char *d_out, void *stream);
-/* images worked on per launch set (default 256); arenas grow to match */
+/* most images worked on per launch set (default 256); arenas grow to match */
 void sift_set_batch_chunk(int images_per_launch);
 /* Detection is sparse: the pyramid pass queues the pixels that pass the contrast
  * test and only those are examined further.  n = first-octave queue capacity per
@@ -164,6 +164,13 @@ int sift_get_group_counts(int streamIdx, unsigned *accepted, unsigned *queued, i
  * h_dst NULL: only the geometry is returned.  Returns 0 or -1. */
 int sift_debug_read_planes(int slot, int image, int octave, float *h_dst, long dst_floats,
                            int *width, int *pitch, int *height);
+/* Where image i of the most recent batch of n images sits for sift_debug_read_planes
+ * (a batch is cut into launch sets that take turns on the lanes).  Returns 0, or -1 if
+ * a later launch set has reused that arena. */
+int sift_debug_batch_slot(int n, int i, int *slot, int *image);
+/* rows per strip of the pyramid pass; 0 (default) = chosen per launch from the image
+ * size and the number of images.  Results do not depend on it. */
+void sift_set_strip_rows(int rows);
 /* launch sets in flight at once, each on a private stream and arena: 1 or 2
  * (default 2: the short kernels of the small octaves of one set overlap the
  * long kernels of the other) */
@@ -227,6 +234,13 @@ void sift_timing_enable(int on);
 /* total milliseconds and number of launches per kernel since the last reset */
 int sift_timing_read(int kernel, double *ms_total, long *launches);
 void sift_timing_reset(void);
+
+/* The rate of a plain device-to-device copy on the current GPU (a buffer of `bytes` bytes
+ * copied to another, 16 bytes per lane; best of `repeats` passes; bytes read plus bytes
+ * written per second, in GB/s): what the memory system gives a kernel that only moves
+ * bytes, to price bandwidth-bound kernels against beside the data-sheet figure.
+ * Allocates and frees its two buffers.  Returns 0 or a negative error. */
+int sift_measure_copy_ceiling(size_t bytes, int repeats, double *gbytes_per_s);
 
 /* ---- synthetic input (deterministic, no dependencies) ---------------------
  * 128 + value noise + Gaussian blobs + pixel noise, clamped to [0,255] and

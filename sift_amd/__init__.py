@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsift_amd.so")
+# SIFT_AMD_LIB names another build of the same library (kernel experiments); no fallback either way
+LIB_PATH = os.environ.get("SIFT_AMD_LIB") or os.path.join(_HERE, "libsift_amd.so")
 
 MAX_SLOTS = 8
 K_ROW_BLUR, K_COL_BLUR_DOG, K_DETECT, K_KEYPOINT, K_PYRAMID, K_VERIFY, K_ALIAS = 0, 1, 2, 3, 4, 5, 6
@@ -75,6 +76,8 @@ SYMBOLS = {
     "sift_set_queue_cap": (None, [C.c_int]),
     "sift_get_group_counts": (C.c_int, [C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.c_int]),
     "sift_debug_read_planes": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, C.c_long, _ip, _ip, _ip]),
+    "sift_debug_batch_slot": (C.c_int, [C.c_int, C.c_int, _ip, _ip]),
+    "sift_set_strip_rows": (None, [C.c_int]),
     "sift_device_count": (C.c_int, []),
     "sift_set_device": (C.c_int, [C.c_int]),
     "sift_dev_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
@@ -99,6 +102,7 @@ SYMBOLS = {
     "sift_timing_enable": (None, [C.c_int]),
     "sift_timing_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "sift_timing_reset": (None, []),
+    "sift_measure_copy_ceiling": (C.c_int, [C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "sift_synth_image": (None, [_vp, C.c_int, C.c_int, C.c_int, C.c_ulonglong, C.c_int]),
 }
 
@@ -264,6 +268,14 @@ def debug_read_planes(slot, image, octave):
     return out, w.value
 
 
+def debug_batch_slot(n, i):
+    """(slot, image) of image i of the latest batch of n images, for debug_read_planes."""
+    slot, image = C.c_int(), C.c_int()
+    if lib().sift_debug_batch_slot(n, i, C.byref(slot), C.byref(image)):
+        raise SiftError(f"image {i} of a batch of {n} is no longer in an arena")
+    return slot.value, image.value
+
+
 def getPointCount(streamIdx=0):
     n = lib().getPointCount(streamIdx)
     if n < 0:
@@ -367,6 +379,13 @@ def timing_read(kernel):
     ms, n = C.c_double(), C.c_long()
     lib().sift_timing_read(kernel, C.byref(ms), C.byref(n))
     return ms.value, n.value
+
+
+def measure_copy_ceiling(nbytes=2 << 30, repeats=5):
+    """GB/s (read + write) of a plain device copy of nbytes on the current GPU."""
+    v = C.c_double()
+    _ok(lib().sift_measure_copy_ceiling(nbytes, repeats, C.byref(v)))
+    return v.value
 
 
 def shutdown():

@@ -89,6 +89,12 @@ int hl_host_alloc(void **p, size_t bytes);
 int hl_host_free(void *p);
 const char *hl_error_string(int code);
 
+/* rows per strip of the pyramid pass (0 = chosen per launch); for experiments */
+void hl_set_pyramid_strip_rows(int rows);
+
+/* device-to-device copy of `bytes` bytes, best of `repeats` timed passes: read + write GB/s */
+int hl_copy_ceiling(size_t bytes, int repeats, double *gbps);
+
 /* timing */
 void hl_timing_enable(int on);
 int hl_timing_read(int kernel, double *ms, long *launches);

@@ -701,6 +701,32 @@ void sift_set_batch_lanes(int n)
         g_lanes = n;
 }
 
+/* How a batch of n images is cut into launch sets: the fewest sets of at most g_chunk
+ * images, of equal size.  Set k holds images [k*chunk, min(n, (k+1)*chunk)) and runs on
+ * lane k % lanes.  (Cutting a batch that fits one set in two, one per lane, was measured
+ * slower: 48.4 k against 49.8 k images/s at 256 images of 1080p.) */
+static void batch_sets(int n, int *chunk, int *n_sets)
+{
+    const int sets = (n + g_chunk - 1) / g_chunk;
+    *chunk = (n + sets - 1) / sets;
+    *n_sets = (n + *chunk - 1) / *chunk;
+}
+
+int sift_debug_batch_slot(int n, int i, int *slot, int *image)
+{
+    if (n < 1 || i < 0 || i >= n || !slot || !image) return -1;
+    int chunk, n_sets;
+    batch_sets(n, &chunk, &n_sets);
+    const int lanes = n_sets < g_lanes ? n_sets : g_lanes;
+    const int k = i / chunk;
+    if (k + lanes < n_sets) return -1; /* a later set has reused that lane's arena */
+    *slot = BATCH_SLOT + k % lanes;
+    *image = i % chunk;
+    return 0;
+}
+
+void sift_set_strip_rows(int rows) { hl_set_pyramid_strip_rows(rows > 0 ? rows : 0); }
+
 /* h_counts != NULL: the counts go to the host and the call blocks until they are there.
  * Otherwise they go to d_counts (device, n words) and the call returns after enqueueing. */
 static int extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts, unsigned *d_counts,
@@ -723,8 +749,8 @@ static int extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
             set_err("sift_extract_batch: image larger than 65535 pixels on a side");
             break;
         }
-        const int chunk = n < g_chunk ? n : g_chunk;
-        const int n_sets = (n + chunk - 1) / chunk;
+        int chunk, n_sets;
+        batch_sets(n, &chunk, &n_sets);
         const int lanes = n_sets < g_lanes ? n_sets : g_lanes;
         if (ensure_lanes(dev))
             break;
@@ -959,6 +985,11 @@ int sift_stream_destroy(void *s) { WRAP(hl_stream_destroy(s), "sift_stream_destr
 int sift_stream_sync(void *s) { WRAP(hl_stream_sync(s), "sift_stream_sync"); }
 int sift_host_alloc_pinned(void **p, size_t n) { WRAP(hl_host_alloc(p, n), "sift_host_alloc_pinned"); }
 int sift_host_free_pinned(void *p) { WRAP(hl_host_free(p), "sift_host_free_pinned"); }
+
+int sift_measure_copy_ceiling(size_t bytes, int repeats, double *gbytes_per_s)
+{
+    WRAP(hl_copy_ceiling(bytes, repeats, gbytes_per_s), "sift_measure_copy_ceiling");
+}
 
 void sift_timing_enable(int on) { hl_timing_enable(on); }
 int sift_timing_read(int kernel, double *ms, long *launches)

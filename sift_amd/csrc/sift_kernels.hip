@@ -246,21 +246,18 @@ __global__ __launch_bounds__(64) void col_blur_dog_kernel(
 // (yblurKernel's chain).
 //
 // Memory pipeline.  On gfx9-family hardware loads and stores retire through
-// one in-order counter, so a wave can only leave loads in flight across its
-// stores if the compiler can count both exactly -- and its counts are static
-// per instruction, merged over every path that reaches it.  The whole strip is
-// therefore ONE loop over a straight-line chunk of 20 rows in which every row
-// issues the same two loads and S + (S+2) stores unconditionally: load
-// addresses are clamped and the values zeroed with masks; the stores of rows
-// that complete no output row of this strip (the first 18 input rows, and any
-// row past the strip's end in the last chunk) carry an out-of-range buffer
-// offset, which the hardware drops without memory traffic.  The first chunk is
-// peeled off in front of the loop, so the loop is entered in the same counter
-// state its back edge produces.  All 64 lanes store: columns [w, pitch) of the
-// destination planes are scratch.
-// Source rows are fetched FZ_PF rows ahead into registers; the LDS row buffer
-// has two slots so the write of row r+1 is issued a whole step before its
-// first read.
+// one in-order counter.  The source rows travel from HBM straight into LDS
+// (buffer_load ... lds: no register is held while a row is in flight), FZ_PF
+// rows ahead of their use, and every row step issues the same vector-memory
+// operations unconditionally: two source fetches and S+3 stores.  The wait in
+// front of a row's first LDS read is therefore a constant: the number of
+// operations issued since that row's fetch.  Pixels outside the image come
+// back as zeros from the buffer's range check: a column outside [0, w) has an
+// out-of-range lane offset, a row outside [0, h) an out-of-range row offset.
+// The stores of rows that complete no output row of this strip (the first 18
+// input rows, and any row past the strip's end in the last chunk) carry an
+// out-of-range offset too and are dropped by the hardware.  All 64 lanes
+// store: columns [w, pitch) of the destination planes are scratch.
 //
 // SRC_MODE 0: source is a float image (any pitch or alignment)
 //          1: source is an 8-bit image (src points at bytes; pitch and stride in
@@ -269,8 +266,9 @@ __global__ __launch_bounds__(64) void col_blur_dog_kernel(
 //             and even columns (resizeKernel cudaSiftD.cu:544-559 folded into
 //             the fetch; the down-sampled base is never materialised)
 // ---------------------------------------------------------------------------
-constexpr int FZ_PF = 2;
-static_assert(20 % FZ_PF == 0, "the prefetch ring must divide the row chunk");
+constexpr int FZ_PF = 4;            // source rows in flight per wave
+constexpr int FZ_SLOTS = FZ_PF + 1; // LDS row buffers: the rows in flight and the row being read
+static_assert(20 % FZ_SLOTS == 0, "the row buffers must be used in whole turns per row chunk");
 constexpr int FZ_STAGE = 88; // floats staged per row
 constexpr int PQ_CAP = 1024; // contrast candidates one wave can hold per scale between flushes
 constexpr unsigned FZ_DROP = 0xfffffff0u; // per-lane buffer offset past every plane: the store is dropped
@@ -292,7 +290,7 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
 {
     constexpr int NP = S + 3;
     constexpr bool plain = PLAIN; // the detector without tiles ("lowe" profile)
-    __shared__ float lds[2][128];
+    __shared__ float lds[FZ_SLOTS][128];
     // contrast candidates of this strip: pixels whose centre-plane DoG exceeds
     // the detector's threshold (cudaSiftD.cu:293), kept per scale in LDS and
     // flushed to the global queue once, after the last row
@@ -356,52 +354,40 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     float thr[S];
 #pragma unroll
     for (int i = 0; i < S; ++i)
-        thr[i] = (pre && qcount[z * qcount_stride + group0 + i] > (unsigned)qcap) ? __builtin_inff() : contrast;
+        thr[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(
+            (pre && qcount[z * qcount_stride + group0 + i] > (unsigned)qcap) ? __builtin_inff() : contrast))); // wave-uniform: a scalar register
 
-    // ---- source fetch of one row into registers ----
-    // The loads are unconditional (clamped addresses) and pixels outside the
-    // image are zeroed with bit masks, not selects: a select on the loaded
-    // value lets the compiler sink the load under the condition and wait for
-    // it on the spot, which would serialise the whole memory pipeline.
-    // lane j holds staged float j (.x) and, for j < 24, staged float 64+j (.y)
+    // ---- source fetch: one row from HBM into an LDS row buffer ----
+    // lane j fetches staged float j and, for j < 24, staged float 64+j
     constexpr int SX = SRC_MODE == 2 ? 2 : 1; // column and row step in the source
     int col_off[2];
-    unsigned col_mask[2];
     {
         const int xa = x0 - 12 + lane, xb = xa + 64;
         const bool oka = xa >= 0 && xa < w, okb = lane < FZ_STAGE - 64 && xb >= 0 && xb < w;
-        col_off[0] = oka ? SX * xa * ES : 0;
-        col_off[1] = okb ? SX * xb * ES : 0;
-        col_mask[0] = oka ? 0xffffffffu : 0u;
-        col_mask[1] = okb ? 0xffffffffu : 0u;
+        col_off[0] = oka ? SX * xa * ES : (int)FZ_DROP;
+        col_off[1] = okb ? SX * xb * ES : (int)FZ_DROP; // (lanes >= 24 fill unused cells with zeros)
     }
-    auto masked = [](float v, unsigned m) __attribute__((always_inline)) { return __uint_as_float(__float_as_uint(v) & m); };
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float *)&lds[0][0];
     int yi_next = y0 - RADIUS; // rows are fetched strictly in order
-    // The loaded value is only touched when it is staged, FZ_PF rows later; the
-    // row's validity travels beside it as a wave-uniform mask.
-    struct Row { float2v v; unsigned ok; };
-    auto fetch = [&]() __attribute__((always_inline)) -> Row {
+    // The fetches are inline assembly so that the compiler neither tracks them (it would
+    // wait for the youngest of them in front of every LDS read) nor counts them; extra
+    // operations the compiler adds only make the waits below more conservative.
+    auto fetch = [&](const int slot) __attribute__((always_inline)) {
         const int yi = yi_next++;
-        const int yc = min(max(yi, 0), h - 1);
-        const int row = (int)((unsigned)(SX * yc) * (unsigned)src_pitch * (unsigned)ES);
-        Row o;
-        if (SRC_MODE == 1) { // the byte travels as an integer until it is staged
-            o.v.x = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b8(src_rs, col_off[0], row, 0));
-            o.v.y = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b8(src_rs, col_off[1], row, 0));
+        const unsigned row = (yi >= 0 && yi < h) ? (unsigned)(SX * yi) * (unsigned)src_pitch * (unsigned)ES : FZ_DROP;
+        const unsigned dst = lds_base + (unsigned)slot * 512u;
+        if (SRC_MODE == 1) { // a byte arrives as the integer of its value
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_ubyte %1, %2, %3 offen lds" ::"s"(dst), "v"(col_off[0]), "s"(src_rs), "s"(row) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_ubyte %1, %2, %3 offen lds" ::"s"(dst + 256u), "v"(col_off[1]), "s"(src_rs), "s"(row) : "memory");
         } else {
-            o.v.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src_rs, col_off[0], row, 0));
-            o.v.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src_rs, col_off[1], row, 0));
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(dst), "v"(col_off[0]), "s"(src_rs), "s"(row) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(dst + 256u), "v"(col_off[1]), "s"(src_rs), "s"(row) : "memory");
         }
-        o.ok = (yi >= 0 && yi < h) ? 0xffffffffu : 0u;
-        return o;
     };
-    auto pixel = [](float raw) __attribute__((always_inline)) {
-        return SRC_MODE == 1 ? (float)(__float_as_uint(raw) & 0xffu) : raw;
-    };
-    auto stage = [&](int slot, const Row &o) __attribute__((always_inline)) {
-        lds[slot][lane] = masked(pixel(o.v.x), col_mask[0] & o.ok);
-        lds[slot][lane + 64] = masked(pixel(o.v.y), col_mask[1] & o.ok); // lanes >= 24 write unused cells
-    };
+    // vector-memory operations issued between a row's fetch and its first read: the NP
+    // stores of the step that fetched it, FZ_PF - 1 whole steps, and this step's fetch
+    constexpr int FZ_WAIT = NP + (NP + 2) * (FZ_PF - 1) + 2;
+    static_assert(FZ_WAIT < 64, "the counter holds 63");
 
     constexpr int NPAIR = NP / 2;
     constexpr bool ODD = (NP & 1) != 0;
@@ -414,16 +400,16 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
         accs[k] = 0.f;
     }
 
-    Row g[FZ_PF];
-
     // lanes the detector pre-filter may queue, as wave masks
     const unsigned long long pre_mask = __ballot(pre_lane), pre_mask0 = __ballot(pre_lane0);
 
     // appends the lanes of `hits` to the wave's list of scale i as pixels of row y
     auto push = [&](const int i, const unsigned long long hits, const int y) __attribute__((always_inline)) {
         if (hits) {
-            const unsigned slot = lq_n[i] + __popcll(hits & ((1ull << lane) - 1ull));
-            if (((hits >> lane) & 1ull) && slot < PQ_CAP) lq[i][slot] = (unsigned)xq | ((unsigned)y << 16);
+            // lanes below this one among the hits: the mask-bit-count instruction needs no per-lane mask register
+            const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(hits >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hits, 0u));
+            const unsigned slot = lq_n[i] + below;
+            if (((hits >> lane) & 1ull) && slot < PQ_CAP) lq[i][slot] = (unsigned)(x0 + lane) | ((unsigned)y << 16);
             lq_n[i] += (unsigned)__popcll(hits);
         }
     };
@@ -437,12 +423,21 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
             const int r = rb + rr;
             // keep each row's instructions together
             __builtin_amdgcn_sched_barrier(0);
-            // row r+1 goes to the other LDS slot; its register is refilled with row r+1+FZ_PF
-            stage((rr + 1) & 1, g[(rr + 1) % FZ_PF]);
-            g[(rr + 1) % FZ_PF] = fetch();
+            // row r + FZ_PF goes to the buffer row r - 1 was read from
+            fetch((rr + FZ_PF) % FZ_SLOTS);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FZ_WAIT) : "memory"); // row r has landed
+            constexpr int slot = rr % FZ_SLOTS;
+            if (SRC_MODE == 1) { // integers to floats, in place (LDS operations of a wave stay in order)
+                const unsigned a0 = __float_as_uint(lds[slot][lane]), a1 = __float_as_uint(lds[slot][lane + 64]);
+                lds[slot][lane] = (float)a0;
+                lds[slot][lane + 64] = (float)a1;
+                // other lanes read these cells: keep the compiler from moving their reads up
+                // (the hardware runs a wave's LDS operations in order)
+                asm volatile("" ::: "memory");
+            }
             float win[TAPS + 1]; // the 20th value only completes the last register pair
 #pragma unroll
-            for (int k = 0; k < 10; ++k) win[k] = lds[rr & 1][lane + 3 + k];
+            for (int k = 0; k < 10; ++k) win[k] = lds[slot][lane + 3 + k];
             float2v vp[NPAIR];
             float vs = 0.f;
 #pragma unroll
@@ -452,7 +447,7 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
                 if (k == 10) {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int q = 10; q < TAPS + 1; ++q) win[q] = lds[rr & 1][lane + 3 + q];
+                    for (int q = 10; q < TAPS + 1; ++q) win[q] = lds[slot][lane + 3 + q];
                     // a packed operand names a register pair: without a defined partner the
                     // last window value may share its pair with a load still in flight, and
                     // the use would wait for all of memory
@@ -463,6 +458,7 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
                 for (int j = 0; j < NPAIR; ++j) vp[j] = pk_fma(tap2(taps, j, k), wk, vp[j]);
                 if (ODD) vs = __builtin_fmaf(tap1(taps, NP - 1, k), win[k], vs);
             }
+#ifndef PYR_EXP_NO_COLUMN_FMA
 #pragma unroll
             for (int k = 0; k < TAPS; ++k) {
                 const int slot = (rr - k + COL_RING) % COL_RING;
@@ -471,9 +467,21 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
                     accp[j][slot] = pk_fma(tap2(taps, j, k), vp[j], k == 0 ? float2v{0.f, 0.f} : accp[j][slot]);
                 if (ODD) accs[slot] = __builtin_fmaf(tap1(taps, NP - 1, k), vs, k == 0 ? 0.f : accs[slot]);
             }
+#else // experiment: what the kernel costs without its column arithmetic
+            {
+                constexpr int slot = (rr - 18 + COL_RING) % COL_RING;
+#pragma unroll
+                for (int j = 0; j < NPAIR; ++j) accp[j][slot] = vp[j];
+                if (ODD) accs[slot] = vs;
+            }
+#endif
             // output row y0 + r - 18 is complete if it belongs to this strip
             const bool valid = r >= 2 * RADIUS && r < nin; // wave-uniform
+#ifdef PYR_EXP_NO_STORES // experiment: what the kernel costs without its write traffic
+            const int vo = out_lane | (int)FZ_DROP;
+#else
             const int vo = out_lane | (valid ? 0 : (int)FZ_DROP);
+#endif
             constexpr int e = (rr - 2 * RADIUS + COL_RING) % COL_RING;
             float b[NP];
 #pragma unroll
@@ -582,20 +590,18 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
         for (int i = 0; i < S; ++i) fill = max(fill, lq_n[i]);
         if (fill > PQ_CAP / 2) flush();
     };
-    // prologue: the first FZ_PF rows
+    // prologue: the first FZ_PF rows, waited for in full, so that the constant wait of the
+    // row loop holds from its first step on (it assumes FZ_PF steps of operations behind a fetch)
 #pragma unroll
-    for (int q = 0; q < FZ_PF; ++q) g[q] = fetch();
-    stage(0, g[0]);
-    g[0] = fetch();
-    // The first chunk stands outside the loop: the loop is then entered in the
-    // counter state its own back edge produces, and the waits inside it are
-    // exact on every trip.
-    chunk(0);
-    int rb = COL_RING;
+    for (int q = 0; q < FZ_PF; ++q) fetch(q);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int rb = 0;
     for (; rb < nin; rb += COL_RING) {
         chunk(rb);
         flush_if_filling();
     }
+    // rows fetched beyond the strip's last are still on their way into this block's LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (PLAIN && pre && __ballot(pend != 0u)) { // the strip's last row has no row below in this wave
 #pragma unroll
         for (int i = 0; i < S; ++i) push(i, __ballot(((pend >> i) | (pend >> (S + i))) & 1u), y0 + rb - 2 * RADIUS - 1);
@@ -2194,6 +2200,23 @@ __global__ __launch_bounds__(256) void gradient_kernel(float *dst, const float *
     dst[g + (long)p * h] = d;
 }
 
+// ---- device copy ceiling ------------------------------------------------------
+// A plain device-to-device copy, 16 bytes per lane, each block a contiguous 16 KB: the
+// rate this GPU's memory system gives a kernel that only moves bytes.  Bandwidth-bound
+// kernels are priced against it beside the data-sheet figure.
+typedef float copy_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void copy_ceiling_kernel(copy_f4 *__restrict__ out, const copy_f4 *__restrict__ in, long n)
+{
+    const long base = (long)blockIdx.x * 1024 + threadIdx.x;
+    copy_f4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (base + u * 256 < n) v[u] = in[base + u * 256];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (base + u * 256 < n) out[base + u * 256] = v[u];
+}
+
 // ---- timing -----------------------------------------------------------------
 struct TimedLaunch {
     int kernel;
@@ -2248,9 +2271,40 @@ inline int chk(hipError_t e) { return e == hipSuccess ? 0 : -(int)e; }
 inline int launch_status() { return chk(hipGetLastError()); }
 inline int idivup(int a, int b) { return (a + b - 1) / b; }
 
+int g_strip_override = 0; // > 0: rows per strip of the pyramid pass, for experiments
+
+// Rows per strip of the fused pyramid pass.  A wave walks its strip in chunks of 20 input
+// rows and needs 18 rows of apron, so a strip of r rows costs 20*ceil((r+18)/20) row steps;
+// the waves of a launch run in rounds of as many as the chip holds at once.  The strips are
+// cut (equal heights) so that rounds x steps per wave is smallest: tall strips when the batch
+// alone fills the chip (1080p, 256 images: 2 strips of 540 rows = 560 steps per column
+// instead of 6 x 200), short ones when a single image has to be spread over all SIMDs.
+int pyramid_strip_rows(int w, int h, int nimg, int n_scales)
+{
+    if (g_strip_override > 0) return g_strip_override < h ? g_strip_override : h;
+    const long slots = 256L * 4 * (n_scales == 2 ? 3 : 2);
+    const long gx = idivup(w, 64);
+    long best_t = -1;
+    int best_rows = h;
+    for (int n = 1; n <= h; ++n) {
+        const int rows = idivup(h, n);
+        if (rows < 2 && n > 1) break;
+        if (n > 1 && rows == idivup(h, n - 1)) continue; // same strips as the last candidate
+        const long strips = idivup(h, rows);
+        const long steps = idivup(rows + 2 * RADIUS, COL_RING);
+        const long rounds = (gx * strips * nimg + slots - 1) / slots;
+        const long t = rounds * steps;
+        if (best_t < 0 || t < best_t) best_t = t, best_rows = rows;
+        if (rounds > 64) break; // more strips only add apron rows from here on
+    }
+    return best_rows;
+}
+
 } // namespace
 
 extern "C" {
+
+void hl_set_pyramid_strip_rows(int rows) { g_strip_override = rows; }
 
 int hl_device_count(void)
 {
@@ -2334,6 +2388,38 @@ void hl_timing_reset(void)
     }
 }
 
+int hl_copy_ceiling(size_t bytes, int repeats, double *gbps)
+{
+    if (bytes < (1u << 20) || repeats < 1 || !gbps) return -1001;
+    const long n = (long)(bytes / 16);
+    void *a = nullptr, *b = nullptr;
+    int r = chk(hipMalloc(&a, (size_t)n * 16));
+    if (!r) r = chk(hipMalloc(&b, (size_t)n * 16));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (!r) r = chk(hipEventCreate(&e0));
+    if (!r) r = chk(hipEventCreate(&e1));
+    if (!r) r = chk(hipMemsetAsync(a, 1, (size_t)n * 16, nullptr));
+    if (!r) r = chk(hipMemsetAsync(b, 0, (size_t)n * 16, nullptr));
+    float best = 0.f;
+    for (int it = 0; it <= repeats && !r; ++it) { // the first pass warms up
+        (void)hipEventRecord(e0, nullptr);
+        hipLaunchKernelGGL(copy_ceiling_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, nullptr,
+                           (copy_f4 *)b, (const copy_f4 *)a, n);
+        (void)hipEventRecord(e1, nullptr);
+        r = chk(hipEventSynchronize(e1));
+        float ms = 0.f;
+        if (!r) r = chk(hipEventElapsedTime(&ms, e0, e1));
+        if (!r && it > 0 && (best == 0.f || ms < best)) best = ms;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (r) return r;
+    *gbps = best > 0.f ? 2.0 * (double)n * 16.0 / ((double)best * 1e-3) / 1e9 : 0.0;
+    return 0;
+}
+
 int hl_row_blur(const float *src, int src_pitch, long src_stride, float *tmp, long tmp_stride,
                 int w, int p, int h, int n_scales, int nimg, const hl_taps *taps, void *stream)
 {
@@ -2409,20 +2495,7 @@ int hl_pyramid(const void *src, int src_w, int src_h, int src_pitch, long src_st
     if ((long)p * h * (n_scales + 3) * 4 >= (long)FZ_DROP || (long)src_pitch * src_h * (src_mode == 1 ? 1 : 4) > 0xffffffffL)
         return -1007;
     if (queue && (!qcount || qcap < 1 || w > 65535 || h > 65535)) return -1008;
-    // strip height 20*m - 18: every strip recomputes an 18-row apron, so strips are as
-    // tall as the launch allows while still giving the chip a few waves per SIMD, and
-    // equal in height so that no strip is a short left-over
-    int m = 11;
-    while (m > 2 && (long)idivup(w, 64) * idivup(h, COL_RING * m - 2 * RADIUS) * nimg < 4096) --m;
-    // a launch that cannot fill the chip anyway (single small images) is bound by
-    // the length of one strip walk: two output rows per strip halve it once more
-    if (m == 2 && (long)idivup(w, 64) * idivup(h, COL_RING * 2 - 2 * RADIUS) * nimg < 1024) m = 1;
-    {
-        const int n_strips = idivup(h, COL_RING * m - 2 * RADIUS);
-        const int m_even = idivup(idivup(h, n_strips) + 2 * RADIUS, COL_RING);
-        if (m_even >= 1 && m_even < m) m = m_even;
-    }
-    const int rows = COL_RING * m - 2 * RADIUS;
+    const int rows = pyramid_strip_rows(w, h, nimg, n_scales);
     dim3 grid(idivup(w, 64), idivup(h, rows), nimg), block(64);
     hipStream_t s = (hipStream_t)stream;
     ScopedTimer t(4, s);

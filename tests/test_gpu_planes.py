@@ -66,8 +66,8 @@ def test_fused_kernel_planes_match_the_oracle(sift, oracle_mod, w, h, S, O, nimg
         d = torch.from_numpy(imgs.astype(np.uint8) if u8 else imgs).cuda()  # the images hold integers
         sift.extract_batch(d, w)
         for i in sorted({0, nimg - 1}):
-            _assert_octaves_equal(sift, oracle_mod, pr, imgs[i], w, BATCH_LANE0, i, O,
-                                  f"{w}x{h} S={S} image {i}")
+            slot, k = sift.debug_batch_slot(nimg, i)
+            _assert_octaves_equal(sift, oracle_mod, pr, imgs[i], w, slot, k, O, f"{w}x{h} S={S} image {i}")
     finally:
         sift.set_params()
 
@@ -126,10 +126,11 @@ def config3(sift, oracle_mod):
 
 
 def test_config3_planes_at_the_bench_geometry(config3, oracle_mod):
-    """256 images per launch: the strip height and grid of the benchmark (182 rows at 1080p)."""
+    """The launch sets, strip heights and grids of the benchmark's batch."""
     c = config3
-    for i in (0, 127, 255):
-        _assert_octaves_equal(c["sift"], oracle_mod, c["pr"], c["imgs"][i], c["w"], BATCH_LANE0, i, 5,
+    for i in (0, 127, 128, 255):
+        slot, k = c["sift"].debug_batch_slot(c["n"], i)
+        _assert_octaves_equal(c["sift"], oracle_mod, c["pr"], c["imgs"][i], c["w"], slot, k, 5,
                               f"config 3 image {i}")
 
 

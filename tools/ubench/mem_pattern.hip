@@ -1,0 +1,192 @@
+// Micro-benchmark: which access pattern of "read one plane, write NPL planes, walking down a
+// strip of rows" the MI355X memory system sustains best.  The fused pyramid kernel moves exactly
+// these bytes; this program moves them with a chosen amount of arithmetic per element, so the
+// memory ceiling of each pattern and how well arithmetic hides behind it can be read off.
+//
+//   VW     floats per lane and row (1, 2 or 4): a wave covers 64*VW columns
+//   WAVES  waves per workgroup, side by side in x
+//   LAYOUT 0 planar (plane i at i*p*h), 1 pixel-interleaved (pixel x holds its NPL values together)
+//   FMAS   dependent-free FMAs per element and plane-row (stands in for the blur arithmetic)
+//   PF     rows fetched ahead
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+template <int VW> struct Vec;
+template <> struct Vec<1> { typedef float T; };
+template <> struct Vec<2> { typedef float2 T; };
+template <> struct Vec<4> { typedef float4 T; };
+
+template <int VW> __device__ __forceinline__ void fma_all(typename Vec<VW>::T &v, float a, float b);
+template <> __device__ __forceinline__ void fma_all<1>(float &v, float a, float b) { v = __builtin_fmaf(v, a, b); }
+template <> __device__ __forceinline__ void fma_all<2>(float2 &v, float a, float b)
+{
+    v.x = __builtin_fmaf(v.x, a, b);
+    v.y = __builtin_fmaf(v.y, a, b);
+}
+template <> __device__ __forceinline__ void fma_all<4>(float4 &v, float a, float b)
+{
+    v.x = __builtin_fmaf(v.x, a, b);
+    v.y = __builtin_fmaf(v.y, a, b);
+    v.z = __builtin_fmaf(v.z, a, b);
+    v.w = __builtin_fmaf(v.w, a, b);
+}
+
+template <int NPL, int VW, int WAVES, int LAYOUT, int FMAS, int PF, int LDSB, int REMAP>
+__global__ __launch_bounds__(64 * WAVES) void strips(float *__restrict__ out, const float *__restrict__ in, int w, int p,
+                                                     int h, int rows, long out_stride, float a, float b)
+{
+    typedef typename Vec<VW>::T V;
+    __shared__ float occ[LDSB / 4 + 1]; // caps the waves per CU
+    if (a == 12345.f) occ[threadIdx.x] = b;
+    if (a == 54321.f) out[0] = occ[threadIdx.x + 1];
+    // XCD-aware remap: each XCD gets a contiguous run of tiles
+    int tx, ty, tz;
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y;
+        const unsigned nwg = gx * gy * gridDim.z;
+        const unsigned orig = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const unsigned q = nwg / 8, r = nwg % 8, xcd = orig % 8;
+        const unsigned t = REMAP ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8 : orig;
+        tx = (int)(t % gx);
+        ty = (int)((t / gx) % gy);
+        tz = (int)(t / (gx * gy));
+    }
+    const int x = (tx * 64 * WAVES + threadIdx.x) * VW;
+    if (x >= w) return;
+    const int y0 = ty * rows, y1 = min(y0 + rows, h);
+    const float *s = in + tz * (long)p * h + x;
+    float *o = out + tz * out_stride;
+    const long plane = (long)p * h;
+    V g[PF];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) g[q] = *reinterpret_cast<const V *>(s + (long)min(y0 + q, h - 1) * p);
+    for (int y = y0; y < y1; y += PF) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            V v = g[q];
+            g[q] = *reinterpret_cast<const V *>(s + (long)min(y + q + PF, h - 1) * p);
+            if (y + q < y1) {
+                V pv[NPL];
+#pragma unroll
+                for (int i = 0; i < NPL; ++i) {
+                    pv[i] = v;
+#pragma unroll
+                    for (int k = 0; k < FMAS; ++k) fma_all<VW>(pv[i], a, b + (float)i);
+                }
+                if (LAYOUT == 0) {
+#pragma unroll
+                    for (int i = 0; i < NPL; ++i) *reinterpret_cast<V *>(o + i * plane + (long)(y + q) * p + x) = pv[i];
+                } else if (LAYOUT == 2) { // planes interleaved row by row
+#pragma unroll
+                    for (int i = 0; i < NPL; ++i) *reinterpret_cast<V *>(o + ((long)(y + q) * NPL + i) * p + x) = pv[i];
+                } else {
+                    // pixel-interleaved: pixel x of row y at ((y*p + x) * NPL); VW pixels per lane are contiguous
+                    float *d = o + ((long)(y + q) * p + x) * NPL;
+                    float t[NPL * VW];
+#pragma unroll
+                    for (int i = 0; i < NPL; ++i)
+#pragma unroll
+                        for (int c = 0; c < VW; ++c) t[c * NPL + i] = reinterpret_cast<const float *>(&pv[i])[c];
+                    if ((NPL * VW) % 4 == 0) {
+#pragma unroll
+                        for (int j = 0; j < NPL * VW / 4; ++j)
+                            reinterpret_cast<float4 *>(d)[j] = float4{t[4 * j], t[4 * j + 1], t[4 * j + 2], t[4 * j + 3]};
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NPL * VW; ++j) d[j] = t[j];
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void flat_copy(float4 *out, const float4 *in, long n)
+{
+    long i = blockIdx.x * 256L + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (; i < n; i += stride) out[i] = in[i];
+}
+__global__ __launch_bounds__(256) void flat_store(float4 *out, long n)
+{
+    long i = blockIdx.x * 256L + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (; i < n; i += stride) out[i] = float4{1.f, 2.f, 3.f, (float)i};
+}
+
+static hipEvent_t e0, e1;
+template <class F> static float best_ms(F f)
+{
+    float best = 1e9;
+    for (int it = 0; it < 4; ++it) {
+        hipEventRecord(e0, 0);
+        f();
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (it && ms < best) best = ms;
+    }
+    return best;
+}
+
+constexpr int NPL = 5;
+static const int W = 1920, H = 1080, P = 1920, NIMG = 128;
+static float *g_out, *g_in;
+
+template <int VW, int WAVES, int LAYOUT, int FMAS, int PF, int LDSB = 0, int REMAP = 1> static void run(int rows)
+{
+    const long plane = (long)P * H;
+    dim3 grid((W + 64 * WAVES * VW - 1) / (64 * WAVES * VW), (H + rows - 1) / rows, NIMG);
+    const float ms = best_ms([&] {
+        hipLaunchKernelGGL((strips<NPL, VW, WAVES, LAYOUT, FMAS, PF, LDSB, REMAP>), grid, dim3(64 * WAVES), 0, 0, g_out, g_in, W, P, H,
+                           rows, plane * NPL, 0.999f, 0.001f);
+    });
+    const double bytes = (double)plane * NIMG * 4 * (NPL + 1);
+    printf("VW=%d waves/WG=%d layout=%s FMA/elem/plane=%3d PF=%d rows=%4d lds=%5d remap=%d: %7.3f ms  %5.2f TB/s  (%.1f us/image)\n", VW, WAVES,
+           LAYOUT == 0 ? "planar" : (LAYOUT == 1 ? "pixel " : "rowint"), FMAS, PF, rows, LDSB, REMAP, ms, bytes / ms / 1e9, ms * 1e3 / NIMG);
+    fflush(stdout);
+}
+
+int main()
+{
+    const long plane = (long)P * H;
+    hipMalloc(&g_out, plane * NPL * NIMG * 4);
+    hipMalloc(&g_in, plane * NIMG * 4);
+    hipMemset(g_in, 0, plane * NIMG * 4);
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    {
+        const long n = plane * NIMG / 4;
+        float ms = best_ms([&] { hipLaunchKernelGGL(flat_copy, dim3(256 * 16), dim3(256), 0, 0, (float4 *)g_out, (const float4 *)g_in, n); });
+        printf("flat float4 copy: %.3f ms  %.2f TB/s (read + write)\n", ms, 2.0 * n * 16 / ms / 1e9);
+        const long m = plane * NPL * NIMG / 4;
+        ms = best_ms([&] { hipLaunchKernelGGL(flat_store, dim3(256 * 16), dim3(256), 0, 0, (float4 *)g_out, m); });
+        printf("flat float4 store: %.3f ms  %.2f TB/s\n", ms, (double)m * 16 / ms / 1e9);
+    }
+    // occupancy: 8 / 5 / 3 / 2 waves per SIMD (LDS per one-wave block caps the waves per CU)
+    run<1, 1, 0, 0, 4>(540);
+    run<1, 1, 0, 0, 4, 8000>(540);
+    run<1, 1, 0, 0, 4, 13000>(540);
+    run<1, 1, 0, 0, 4, 20000>(540);
+    run<1, 1, 0, 0, 8, 13000>(540);
+    run<1, 1, 0, 38, 4, 13000>(540);
+    run<1, 1, 0, 38, 8, 13000>(540);
+    run<2, 1, 0, 0, 4, 13000>(540);
+    run<4, 1, 0, 0, 4, 13000>(540);
+    run<4, 1, 0, 0, 4, 40000>(540);
+    // no XCD remap
+    run<1, 1, 0, 0, 4, 0, 0>(540);
+    run<1, 1, 0, 0, 4, 13000, 0>(540);
+    // planes interleaved row by row
+    run<1, 1, 2, 0, 4>(540);
+    run<1, 1, 2, 0, 4, 13000>(540);
+    run<4, 1, 2, 0, 4>(540);
+    run<1, 4, 2, 0, 4, 52000>(540);
+    // short strips
+    run<1, 1, 0, 0, 4, 13000>(60);
+    run<1, 1, 0, 0, 4, 13000>(1080);
+    return 0;
+}
