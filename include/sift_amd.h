@@ -133,6 +133,25 @@ int sift_extract_batch_u8(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts
 int sift_extract_batch_async(SiftPoint *d_pts, unsigned char *d_meta, unsigned *d_counts,
                              const void *d_imgs, int imgs_u8, long img_stride, int n,
                              int width, int pitch, int height, void *stream);
+/* One image without any allocation.  No counterpart in the reference (its extractSift
+ * allocates and frees a dozen buffers per octave, cudaSiftH.cu:22-24,58,158-177); for callers
+ * that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  A variant of sift_extract_batch_async for n = 1 float image: the same
+ * kernels, with every scratch buffer (blur planes, counters, candidate queues and lists)
+ * taken from one static 32 MiB device array instead of the arenas the other entries
+ * allocate on first use.  d_count (device, one word) receives the clamped point count,
+ * d_pts (device, max_points entries) the points; the call clears d_count itself, queues its
+ * work on `stream` and returns.  It calls no hipMalloc, hipFree or other allocating routine
+ * (the address of the static array is looked up on the first call per device, or by
+ * initDeviceVariables; call either once before capturing).
+ * Limit: the image's scratch must fit the static array, else -1 with a message that names
+ * both sizes; 1024x575 at 3 scales and 4 octaves fits (19 MB), 1920x1080 does not.
+ * Every call on a GPU uses that GPU's one array: calls that overlap on one GPU race (queue
+ * them on one stream, or order them with events).  Returns 0 or -1. */
+int sift_extract_noalloc(SiftPoint *d_pts, unsigned *d_count, const float *d_img, int width,
+                         int pitch, int height, void *stream);
+/* size of that static array in bytes */
+size_t sift_noalloc_scratch_bytes(void);
 /* 8-bit descriptors (no counterpart in the reference, whose descriptors are
  * float and L1-normalised, cudaSiftD.cu:186-200): d_out[128*j + k] =
  * min(255, round(512 * d_pts[j].data[k])) for the first n points.  Asynchronous

@@ -70,6 +70,8 @@ SYMBOLS = {
     "sift_extract_batch_u8": (C.c_int, [_vp, _vp, _ip, _vp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "sift_extract_batch_async": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int,
                                            C.c_int, _vp]),
+    "sift_extract_noalloc": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "sift_noalloc_scratch_bytes": (C.c_size_t, []),
     "sift_quantize_descriptors": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "sift_set_batch_chunk": (None, [C.c_int]),
     "sift_set_batch_lanes": (None, [C.c_int]),

@@ -92,6 +92,11 @@ const char *hl_error_string(int code);
 /* rows per strip of the pyramid pass (0 = chosen per launch); for experiments */
 void hl_set_pyramid_strip_rows(int rows);
 
+/* The static device buffer behind the entry point that allocates nothing: the current
+ * device's address of it (looked up on the first call per device) and its size. */
+int hl_scratch(void **ptr, size_t *bytes);
+size_t hl_scratch_bytes(void);
+
 /* device-to-device copy of `bytes` bytes, best of `repeats` timed passes: read + write GB/s */
 int hl_copy_ceiling(size_t bytes, int repeats, double *gbps);
 

@@ -318,25 +318,19 @@ static int ensure_slot_counter(int dev)
     return 0;
 }
 
-/* Plans (or re-plans) the per-image arena: per octave the S+3 blur planes.  A DoG
- * value is formed where it is read (one subtraction of two neighbouring planes,
- * cudaSiftH.cu:190), so DoG planes are never stored.  Every octave has its own
- * planes so that all pyramid passes can be queued back to back and detection
- * can run once, over all octaves, afterwards. */
-static int ensure_arena(slot_ctx *c, int w, int h, int oct0, int nimg)
+/* Plans the per-image arena: per octave the S+3 blur planes.  A DoG value is formed
+ * where it is read (one subtraction of two neighbouring planes, cudaSiftH.cu:190), so DoG
+ * planes are never stored.  Every octave has its own planes so that all pyramid passes can
+ * be queued back to back and detection can run once, over all octaves, afterwards.
+ * Fills the geometry of *c (no pointers) and returns the bytes of each of the five regions
+ * for nimg images: arena, counters, queues, accepted lists, refined-point records. */
+static void plan_arena(slot_ctx *c, int w, int h, int oct0, int nimg, int queue_cap, size_t bytes[5])
 {
     const int S = g_params.n_scales, O = g_params.n_octaves, cap = g_params.max_points;
     const int lowe = g_params.profile == SIFT_PROFILE_LOWE, up = lowe && g_params.upsample;
-    if (c->valid && c->w == w && c->h == h && c->S == S && c->O == O && c->oct0 == oct0 &&
-        c->cap == cap && c->nimg >= nimg && c->queue_cap == g_queue_cap &&
-        c->profile == g_params.profile && c->upsample == up)
-        return 0;
-    if (c->valid && drain_slot(c, "draining slot")) /* geometry changed: its memory goes away */
-        return -1;
-    free_slot(c);
-
+    memset(c, 0, sizeof *c);
     long off = 0, qoff = 0;
-    int ww = up ? 2 * w : w, hh = up ? 2 * h : h, qc = g_queue_cap > 0 ? g_queue_cap : 1;
+    int ww = up ? 2 * w : w, hh = up ? 2 * h : h, qc = queue_cap > 0 ? queue_cap : 1;
     const int n_oct = O - oct0 + (up ? 1 : 0);
     if (up) {
         c->up_off = 0;
@@ -357,26 +351,7 @@ static int ensure_arena(slot_ctx *c, int w, int h, int oct0, int nimg)
     }
     c->queue_stride = qoff;
     c->arena_stride = off;
-    const int groups = n_oct * S;
-    void *p = NULL;
-    int r = hl_malloc(&p, sizeof(float) * (size_t)off * nimg);
-    if (r) return fail_hl(r, "allocating arena");
-    c->arena = (float *)p;
-    r = hl_malloc(&p, sizeof(unsigned) * COUNT_WORDS * (size_t)nimg);
-    if (r) return fail_hl(r, "allocating group counters");
-    c->counts = (unsigned *)p;
-    r = hl_malloc(&p, sizeof(unsigned) * (size_t)c->queue_stride * nimg);
-    if (r) return fail_hl(r, "allocating candidate queue");
-    c->queue = (unsigned *)p;
-    c->cand_stride = (long)groups * cap;
-    r = hl_malloc(&p, sizeof(unsigned) * (size_t)c->cand_stride * nimg);
-    if (r) return fail_hl(r, "allocating candidate lists");
-    c->cand = (unsigned *)p;
-    if (lowe) {
-        r = hl_malloc(&p, 16 * (size_t)c->cand_stride * nimg);
-        if (r) return fail_hl(r, "allocating refined-point records");
-        c->sub = p;
-    }
+    c->cand_stride = (long)n_oct * S * cap;
     c->n_oct = n_oct;
     c->profile = g_params.profile;
     c->upsample = up;
@@ -387,7 +362,47 @@ static int ensure_arena(slot_ctx *c, int w, int h, int oct0, int nimg)
     c->oct0 = oct0;
     c->cap = cap;
     c->nimg = nimg;
-    c->queue_cap = g_queue_cap;
+    c->queue_cap = queue_cap;
+    bytes[0] = sizeof(float) * (size_t)off * nimg;
+    bytes[1] = sizeof(unsigned) * COUNT_WORDS * (size_t)nimg;
+    bytes[2] = sizeof(unsigned) * (size_t)c->queue_stride * nimg;
+    bytes[3] = sizeof(unsigned) * (size_t)c->cand_stride * nimg;
+    bytes[4] = lowe ? 16 * (size_t)c->cand_stride * nimg : 0;
+}
+
+/* Plans (or re-plans) a slot and allocates its regions. */
+static int ensure_arena(slot_ctx *c, int w, int h, int oct0, int nimg)
+{
+    const int S = g_params.n_scales, O = g_params.n_octaves, cap = g_params.max_points;
+    const int lowe = g_params.profile == SIFT_PROFILE_LOWE, up = lowe && g_params.upsample;
+    if (c->valid && c->w == w && c->h == h && c->S == S && c->O == O && c->oct0 == oct0 &&
+        c->cap == cap && c->nimg >= nimg && c->queue_cap == g_queue_cap &&
+        c->profile == g_params.profile && c->upsample == up)
+        return 0;
+    if (c->valid && drain_slot(c, "draining slot")) /* geometry changed: its memory goes away */
+        return -1;
+    free_slot(c);
+
+    size_t bytes[5];
+    plan_arena(c, w, h, oct0, nimg, g_queue_cap, bytes);
+    void *p = NULL;
+    int r = hl_malloc(&p, bytes[0]);
+    if (r) return fail_hl(r, "allocating arena");
+    c->arena = (float *)p;
+    r = hl_malloc(&p, bytes[1]);
+    if (r) return fail_hl(r, "allocating group counters");
+    c->counts = (unsigned *)p;
+    r = hl_malloc(&p, bytes[2]);
+    if (r) return fail_hl(r, "allocating candidate queue");
+    c->queue = (unsigned *)p;
+    r = hl_malloc(&p, bytes[3]);
+    if (r) return fail_hl(r, "allocating candidate lists");
+    c->cand = (unsigned *)p;
+    if (bytes[4]) {
+        r = hl_malloc(&p, bytes[4]);
+        if (r) return fail_hl(r, "allocating refined-point records");
+        c->sub = p;
+    }
     r = hl_event_create(&c->done);
     if (r) return fail_hl(r, "creating slot event");
     c->valid = 1;
@@ -506,9 +521,11 @@ static int enqueue_extract(slot_ctx *c, SiftPoint *pts, unsigned char *meta, con
     if (r) return fail_hl(r, "keypoint kernel");
     r = hl_finalize_counts(base_count, c->counts, COUNT_WORDS, ka.n_groups, cap, nimg, stream);
     if (r) return fail_hl(r, "count update");
-    r = hl_event_record(c->done, stream);
-    if (r) return fail_hl(r, "recording slot event");
-    c->busy = 1;
+    if (c->done) { /* (the entry that allocates nothing has no event: its caller orders by stream) */
+        r = hl_event_record(c->done, stream);
+        if (r) return fail_hl(r, "recording slot event");
+        c->busy = 1;
+    }
     return 0;
 }
 
@@ -524,6 +541,14 @@ void initDeviceVariables(void)
 {
     const int dev = lock_device("initDeviceVariables");
     if (dev < 0) return;
+    {
+        /* set-up work that may allocate happens here, not in the entry that must not:
+         * the device's address of the static scratch buffer is looked up once */
+        void *base = NULL;
+        size_t have = 0;
+        int r = hl_scratch(&base, &have);
+        if (r) fail_hl(r, "initDeviceVariables: static scratch buffer");
+    }
     if (ensure_slot_counter(dev) == 0) {
         /* the reference's cudaMemcpyToSymbol is ordered after all earlier work */
         int r = hl_device_sync();
@@ -678,6 +703,68 @@ int sift_debug_read_planes(int slot, int image, int octave, float *h_dst, long d
     unlock_device(dev);
     return rc;
 }
+
+/* ---- one image, no allocation ------------------------------------------------------ */
+#define NOALLOC_QUEUE_CAP 16384 /* first-octave candidates per scale before the dense detector takes over */
+
+int sift_extract_noalloc(SiftPoint *d_pts, unsigned *d_count, const float *d_img, int width, int pitch,
+                         int height, void *stream)
+{
+    int rc = -1;
+    const int dev = lock_device("sift_extract_noalloc");
+    if (dev < 0) return -1;
+    do {
+        if (tables_ok())
+            break;
+        if (!d_pts || !d_count || !d_img || width < 1 || height < 1 || pitch < width) {
+            set_err("sift_extract_noalloc: bad arguments (w=%d pitch=%d h=%d)", width, pitch, height);
+            break;
+        }
+        if (width > 65535 || height > 65535) {
+            set_err("sift_extract_noalloc: image larger than 65535 pixels on a side");
+            break;
+        }
+        void *base = NULL;
+        size_t have = 0;
+        int r = hl_scratch(&base, &have); /* the device's copy of the static buffer (looked up once per device) */
+        if (r) {
+            fail_hl(r, "sift_extract_noalloc: static scratch buffer");
+            break;
+        }
+        slot_ctx c;
+        size_t bytes[5], off[5], need = 0;
+        plan_arena(&c, width, height, 0, 1, NOALLOC_QUEUE_CAP, bytes);
+        for (int k = 0; k < 5; ++k) {
+            off[k] = need;
+            need += (bytes[k] + 255) & ~(size_t)255;
+        }
+        if (need > have) {
+            set_err("sift_extract_noalloc: a %dx%d image with %d scales, %d octaves and max_points %d needs %zu "
+                    "bytes of scratch, the static buffer holds %zu",
+                    width, height, c.S, c.O, c.cap, need, have);
+            break;
+        }
+        char *b = (char *)base;
+        c.arena = (float *)(b + off[0]);
+        c.counts = (unsigned *)(b + off[1]);
+        c.queue = (unsigned *)(b + off[2]);
+        c.cand = (unsigned *)(b + off[3]);
+        c.sub = bytes[4] ? (void *)(b + off[4]) : NULL;
+        /* the list starts empty: the count is an output, not an accumulator as in extractSift */
+        r = hl_memset_async(d_count, 0, sizeof(unsigned), stream);
+        if (r) {
+            fail_hl(r, "sift_extract_noalloc: clearing the count");
+            break;
+        }
+        if (enqueue_extract(&c, d_pts, NULL, d_img, 0, 0, 1, pitch, 0, d_count, stream))
+            break;
+        rc = 0;
+    } while (0);
+    unlock_device(dev);
+    return rc;
+}
+
+size_t sift_noalloc_scratch_bytes(void) { return hl_scratch_bytes(); }
 
 /* ---- batch ------------------------------------------------------------------ */
 static int ensure_lanes(int dev)

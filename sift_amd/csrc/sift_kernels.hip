@@ -2200,6 +2200,19 @@ __global__ __launch_bounds__(256) void gradient_kernel(float *dst, const float *
     dst[g + (long)p * h] = d;
 }
 
+// ---- static scratch -------------------------------------------------------------
+// Scratch of the entry point that allocates nothing (sift_extract_noalloc): blur planes,
+// counters, candidate queues and lists of ONE image.  Every GPU the library runs on holds
+// its own copy of the array, at its own address, until the process ends.  In host code the
+// array's name is only a handle for hipGetSymbolAddress: the address that kernels, memsets
+// and copies use is the one looked up below, per device.
+constexpr size_t SCRATCH_BYTES = 32u << 20;
+static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
+
+constexpr int SCRATCH_MAX_DEV = 16;
+std::mutex g_scratch_mu;
+void *g_scratch_ptr[SCRATCH_MAX_DEV]; // per device, nullptr until looked up
+
 // ---- device copy ceiling ------------------------------------------------------
 // A plain device-to-device copy, 16 bytes per lane, each block a contiguous 16 KB: the
 // rate this GPU's memory system gives a kernel that only moves bytes.  Bandwidth-bound
@@ -2386,6 +2399,25 @@ void hl_timing_reset(void)
         g_ms[i] = 0;
         g_launches[i] = 0;
     }
+}
+
+size_t hl_scratch_bytes(void) { return SCRATCH_BYTES; }
+
+int hl_scratch(void **ptr, size_t *bytes)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SCRATCH_MAX_DEV) return -1001;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) { // once per device, with that device current
+        void *p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return chk(e);
+        if (!p) return -1009;
+        g_scratch_ptr[dev] = p;
+    }
+    *ptr = g_scratch_ptr[dev];
+    *bytes = SCRATCH_BYTES;
+    return 0;
 }
 
 int hl_copy_ceiling(size_t bytes, int repeats, double *gbps)
