@@ -71,6 +71,8 @@ def lib():
         L.oracle_extract.argtypes = [pp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, ip]
         L.oracle_extract_batch.argtypes = [pp, fp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_void_p, ip, C.c_int]
+        L.oracle_ambiguity_report.argtypes = [pp, fp, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_long)]
+        L.oracle_ambiguity_report.restype = None
         L.oracle_gray_q14.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.oracle_gray_q14.restype = None
         L.oracle_format_points.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_long]
@@ -234,6 +236,21 @@ def extract_batch(pr, imgs, w=None, n_threads=1):
     lib().oracle_extract_batch(C.byref(pr), _fp(imgs), h * p, n, w, p, h, pts.ctypes.data,
                                counts.ctypes.data_as(C.POINTER(C.c_int)), n_threads)
     return pts, counts
+
+
+AMBIGUITY_FIELDS = ("accepted", "accepted_near_edge_limit", "rejected_near_edge_limit",
+                    "accepted_near_contrast_limit", "rejected_near_contrast_limit",
+                    "edge_decisions_that_depend_on_rounding", "of_those_in_the_output")
+
+
+def ambiguity_report(pr, img, w=None, tol=1e-3):
+    """Threshold decisions of cudaSiftD.cu:288-293 within `tol` of their limit, and edge decisions
+    that change under FMA contraction / double-width pow / reciprocal division, as a dict."""
+    img = np.ascontiguousarray(img, np.float32)
+    h, p = img.shape
+    out = (C.c_long * 7)()
+    lib().oracle_ambiguity_report(C.byref(pr), _fp(img), p if w is None else w, p, h, tol, out)
+    return dict(zip(AMBIGUITY_FIELDS, [int(v) for v in out]))
 
 
 def gray_q14(rgb):

@@ -391,6 +391,113 @@ int oracle_find_extrema_closed(const OracleParams *pr, const float *dog3, const 
     return n;
 }
 
+/* How firm are the two float threshold decisions of cudaSiftD.cu:288-293?  The reference was
+ * built by a compiler this restatement cannot see: whether nvcc contracted Dxx*Dyy + Dxy^2
+ * into an FMA, whether pow(float, 2) ran in double, and whether the division was the IEEE
+ * one are all unknowable here.  For every pixel that passes the rank and border tests this
+ * counts, into out[0..6]:
+ *   0 accepted points                         1 accepted, |trace^2/det - limit| < tol
+ *   2 rejected by the edge test alone, within tol of the limit
+ *   3 accepted, ||D| - contrast| < tol        4 rejected by the contrast test alone, within tol
+ *   5 pixels whose edge decision differs between this restatement's arithmetic (separate
+ *     float multiply, float add, IEEE divide) and any of: det by fmaf(Dxx, Dyy, Dxy*Dxy),
+ *     det by fmaf(Dxy, Dxy, Dxx*Dyy), det summed in double and rounded once, quotient by a
+ *     rounded reciprocal
+ *   6 of those, the ones that also pass the contrast test (their presence in the output
+ *     depends on the compiler) */
+void oracle_extrema_ambiguity(const OracleParams *pr, const float *dog3, const float *hess3, int w,
+                              int p, int h, float tol, long *out)
+{
+    long gDim = (long)p * h;
+    const float rhs = (pr->r_thresh * pr->r_thresh) / pr->r_thresh;
+    for (int y = 9; y < h - 8; ++y)
+        for (int x = 9; x < w - 8; ++x) {
+            int tile = (x % XT_DATAX) / XT_BDIM;
+            if (tile == 1)
+                continue;
+            float pv;
+            int r = oracle_pixel_rank(dog3, w, p, h, x, y, &pv);
+            if (tile == 2) {
+                r += oracle_pixel_rank(dog3, w, p, h, x - 64, y, NULL);
+                r += oracle_pixel_rank(dog3, w, p, h, x - 32, y, NULL);
+            }
+            if (r != 9)
+                continue;
+            long g = x + (long)p * y;
+            float Dxx = hess3[g], Dyy = hess3[g + gDim], Dxy = hess3[g + 2 * gDim];
+            float trace = Dxx + Dyy;
+            float tt = trace * trace;
+            float prod = Dxx * Dyy, sq = Dxy * Dxy;
+            float det[4];
+            det[0] = prod + sq;
+            det[1] = fmaf(Dxx, Dyy, sq);
+            det[2] = fmaf(Dxy, Dxy, prod);
+            det[3] = (float)((double)prod + (double)Dxy * (double)Dxy);
+            int edge_ok = (tt / det[0]) < rhs;
+            int differs = 0;
+            for (int k = 1; k < 4; ++k)
+                differs |= ((tt / det[k]) < rhs) != edge_ok;
+            float rcp = 1.0f / det[0];
+            differs |= ((tt * rcp) < rhs) != edge_ok;
+            int con_ok = fabsf(pv) > pr->extrema_thresh;
+            int near_edge = fabsf(tt / det[0] - rhs) < tol;
+            int near_con = fabsf(fabsf(pv) - pr->extrema_thresh) < tol;
+            if (edge_ok && con_ok) {
+                out[0]++;
+                out[1] += near_edge;
+                out[3] += near_con;
+            }
+            if (!edge_ok && con_ok)
+                out[2] += near_edge;
+            if (edge_ok && !con_ok)
+                out[4] += near_con;
+            out[5] += differs;
+            out[6] += differs && con_ok;
+        }
+}
+
+/* The same over every octave and scale of one image (profile ref), out[0..6] summed. */
+void oracle_ambiguity_report(const OracleParams *pr, const float *img, int w, int pitch, int h,
+                             float tol, long *out)
+{
+    int S = pr->n_scales;
+    const float *src = img;
+    float *owned = NULL;
+    int p = pitch;
+    for (int k = 0; k < 7; ++k)
+        out[k] = 0;
+    for (int o = 0; o < pr->n_octaves; ++o) {
+        long gDim = (long)p * h;
+        float *tmp = (float *)calloc((size_t)gDim * (S + 3), sizeof(float));
+        float *blur = (float *)calloc((size_t)gDim * (S + 3), sizeof(float));
+        float *dog = (float *)calloc((size_t)gDim * (S + 2), sizeof(float));
+        float *hess = (float *)calloc((size_t)gDim * 3 * S, sizeof(float));
+        oracle_xblur(pr, src, tmp, w, p, h);
+        oracle_yblur(pr, tmp, blur, w, p, h);
+        oracle_dog(pr, blur, dog, w, p, h);
+        oracle_hessian(pr, blur, hess, w, p, h);
+        for (int i = 0; i < S; ++i)
+            oracle_extrema_ambiguity(pr, dog + i * gDim, hess + (long)i * 3 * gDim, w, p, h, tol, out);
+        float *next = NULL;
+        int w_ = oracle_idivup(w, 2), h_ = oracle_idivup(h, 2), p_ = oracle_ialignup(w_, 128);
+        if (o + 1 < pr->n_octaves) {
+            next = (float *)calloc((size_t)p_ * h_, sizeof(float));
+            oracle_downsample(blur + (long)S * gDim, next, w, p, h);
+        }
+        free(tmp);
+        free(blur);
+        free(dog);
+        free(hess);
+        free(owned);
+        owned = next;
+        src = next;
+        w = w_;
+        h = h_;
+        p = p_;
+    }
+    free(owned);
+}
+
 /* Literal simulation: one shared array per block, the three cooperative tile
  * loads of cudaSiftD.h:43-78 run to completion one after another (each ends in
  * a barrier), then every thread runs the loop of cudaSiftD.cu:263-304. */

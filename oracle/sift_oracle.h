@@ -144,6 +144,14 @@ int oracle_extract_batch(const OracleParams *pr, const float *imgs, long img_str
                          int w, int pitch, int h, OracleSiftPoint *pts, int *counts,
                          int n_threads);
 
+/* How many threshold decisions of cudaSiftD.cu:288-293 sit within `tol` of their limit, and how
+ * many edge decisions change under roundings a CUDA compiler may have chosen (FMA contraction,
+ * double-width pow, reciprocal division); see sift_oracle.c for the seven counters of out[]. */
+void oracle_extrema_ambiguity(const OracleParams *pr, const float *dog3, const float *hess3, int w,
+                              int p, int h, float tol, long *out);
+void oracle_ambiguity_report(const OracleParams *pr, const float *img, int w, int pitch, int h,
+                             float tol, long *out);
+
 /* OpenCV grayscale load as pinned by Sift/result/result.ppm (utils.cc:13):
  * Y = (1868*B + 9617*G + 4899*R + 8192) >> 14 */
 void oracle_gray_q14(const unsigned char *rgb, int npix, unsigned char *gray);

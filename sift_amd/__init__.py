@@ -330,9 +330,12 @@ def extract_batch(d_imgs, width, want_meta=False, stream=None, d_pts=None):
         raise SiftError("expected a contiguous float32 or uint8 CUDA tensor")
     n, h, p = d_imgs.shape
     cap = get_params().max_points
-    if d_pts is None:
-        d_pts = torch.empty((n * cap, POINT_FLOATS), dtype=torch.float32, device=d_imgs.device)
-    meta = torch.zeros((n * cap, 2), dtype=torch.uint8, device=d_imgs.device) if want_meta else None
+    # buffers are created (and the meta bytes zeroed) on the stream the extraction runs on: a fill
+    # queued on another stream is not ordered against the kernels that write the buffer
+    with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream()):
+        if d_pts is None:
+            d_pts = torch.empty((n * cap, POINT_FLOATS), dtype=torch.float32, device=d_imgs.device)
+        meta = torch.zeros((n * cap, 2), dtype=torch.uint8, device=d_imgs.device) if want_meta else None
     counts = np.zeros(n, np.int32)
     entry = lib().sift_extract_batch_u8 if d_imgs.dtype == torch.uint8 else lib().sift_extract_batch
     rc = entry(_dev_f32(d_pts), C.c_void_p(meta.data_ptr()) if want_meta else None,

@@ -569,7 +569,11 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
             const unsigned n = lq_n[i];
             if (n == 0) continue;
             unsigned base = 0;
-            if (lane == 0) base = atomicAdd(&qcount[z * qcount_stride + group0 + i], n > PQ_CAP ? (unsigned)qcap + 1u : n);
+            // a list that overflowed marks the count with its top bit: however many waves do
+            // so, the count stays above every capacity (sums of poison values could wrap)
+            if (lane == 0)
+                base = n > PQ_CAP ? (atomicOr(&qcount[z * qcount_stride + group0 + i], 0x80000000u) | 0x80000000u)
+                                  : atomicAdd(&qcount[z * qcount_stride + group0 + i], n);
             base = __builtin_amdgcn_readfirstlane(__shfl(base, 0));
             if (n <= PQ_CAP)
                 for (unsigned e = lane; e < n; e += 64)
@@ -941,6 +945,9 @@ __global__ __launch_bounds__(256) void verify_kernel(const float *__restrict__ a
         }
         __syncthreads();
         const unsigned pending = slow_n; // at most 255 kept + 256 new
+        // every thread has read the word before any wave can add to it again in the next turn:
+        // the branch below contains barriers, so the whole block must agree on it
+        __syncthreads();
         if (pending >= 256) {
             run_slow(g, pending - 256, 256);
             __syncthreads();

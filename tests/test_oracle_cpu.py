@@ -321,3 +321,126 @@ def test_quantized_descriptors(oracle_mod):
     pts["data"][1, :] = 1.0
     q = oracle_mod.quantize_descriptors(pts)
     assert q[0, :4].tolist() == [0, 102, 1, 1] and np.all(q[1] == 255)
+
+
+# ---- order-free check of the histogram sums ------------------------------------------------
+# The reference leaves its orientation and descriptor sums to shared-memory atomics
+# (cudaSiftD.cu:77, 169): no order is defined.  The oracle (and the GPU) fix one order.  Here
+# every histogram is summed again in double precision with numpy's own (pairwise) order: the
+# oracle's argmax must be the double-precision argmax unless the two leading bins tie to within
+# float rounding, and its descriptors must agree to 1/512 (half a step of an 8-bit descriptor),
+# so the fixed order is shown to sit inside the tolerance, not to define the result.
+def _bins(theta, nbins):
+    theta = theta.astype(np.float32)
+    theta = np.where(theta < 0, theta + np.float32(360), theta).astype(np.float32)
+    theta = np.fmod(theta, np.float32(360)).astype(np.float32)
+    return np.floor(theta / np.float32(360.0 / nbins)).astype(np.int64)
+
+
+def _free_order_orientation(mag, dirn, g16, x, y):
+    ys, xs = np.arange(y - 7, y + 9), np.arange(x - 7, x + 9)
+    m = mag[np.ix_(ys, xs)].astype(np.float64)
+    wgt = m * g16.astype(np.float64)[None, :] * g16.astype(np.float64)[:, None]
+    return np.bincount(_bins(dirn[np.ix_(ys, xs)], 32).ravel(), weights=wgt.ravel(), minlength=32)
+
+
+def _free_order_descriptor(oracle, mag, dirn, w, h, d16, x, y, orientation_deg):
+    c32, s32 = oracle.rotation_table()
+    k = int(np.float32(orientation_deg) / np.float32(11.25)) & 31
+    cs, sn = c32[k], s32[k]
+    f = np.float32
+    t = np.arange(16, dtype=np.float32) - f(7.5)
+    dx, dy = np.meshgrid(t, t)  # [ty][tx]
+    u = (dx * cs).astype(f) + (dy * sn).astype(f)
+    v = (dy * cs).astype(f) - (dx * sn).astype(f)
+    px, py = (f(x) + u).astype(f), (f(y) + v).astype(f)
+    fx, fy = np.floor(px), np.floor(py)
+    ax, ay = (px - fx).astype(np.float64), (py - fy).astype(np.float64)
+    x0, x1 = np.clip(fx.astype(int), 0, w - 1), np.clip(fx.astype(int) + 1, 0, w - 1)
+    y0, y1 = np.clip(fy.astype(int), 0, h - 1), np.clip(fy.astype(int) + 1, 0, h - 1)
+
+    def bilinear(pl, prec):
+        a = lambda z: z.astype(prec)
+        top = a(pl[y0, x0]) + a(ax) * (a(pl[y0, x1]) - a(pl[y0, x0]))
+        bot = a(pl[y1, x0]) + a(ax) * (a(pl[y1, x1]) - a(pl[y1, x0]))
+        return top + a(ay) * (bot - top)
+
+    m = bilinear(mag, np.float64)
+    # the bin is a per-sample decision, not a sum: taken as the oracle takes it, in single precision
+    ax32, ay32 = (px - fx).astype(f), (py - fy).astype(f)
+    lerp = lambda a, b, tt: (a.astype(np.float64) + tt.astype(np.float64) * (b.astype(f) - a.astype(f)).astype(np.float64)).astype(f)
+    top = lerp(dirn[y0, x0], dirn[y0, x1], ax32)
+    bot = lerp(dirn[y1, x0], dirn[y1, x1], ax32)
+    d = lerp(top, bot, ay32)
+    wgt = m * d16.astype(np.float64)[None, :] * d16.astype(np.float64)[:, None]
+    cell = (np.arange(16) // 4)
+    idx = _bins(d, 8) + 8 * cell[None, :] + 32 * cell[:, None]
+    hist = np.bincount(idx.ravel(), weights=wgt.ravel(), minlength=128)
+    hist = hist / hist.sum()
+    hist = np.minimum(hist, 0.2)
+    return hist / hist.sum(), d
+
+
+@pytest.mark.parametrize("w,h,S,seed,dense", [(640, 480, 3, 1, False), (480, 360, 2, 11, True)])
+def test_fixed_summation_orders_sit_inside_the_tolerances(oracle_mod, sift, w, h, S, seed, dense):
+    oracle = oracle_mod
+    pr = oracle.params(n_scales=S, n_octaves=2, max_points=20000)
+    img = sift.synth_image(w, h, seed=seed, dense=dense)
+    pts, meta, total = oracle.extract(pr, img, w)
+    assert total == len(pts) > 10
+    _, wnd, d16 = oracle.tables(pr)
+    src, ow = img, w
+    checked = ties = bin_edge = 0
+    worst = 0.0
+    for o in range(2):
+        oh = src.shape[0]
+        blur = oracle.yblur(pr, oracle.xblur(pr, src, ow), ow)
+        grad = oracle.gradient(pr, blur, ow)
+        for j in np.nonzero(meta[:, 0] == o)[0]:
+            i = int(meta[j, 1])
+            x, y = int(pts["xpos"][j]), int(pts["ypos"][j])
+            mag, dirn = grad[2 * i], grad[2 * i + 1]
+            hist = _free_order_orientation(mag, dirn, wnd[i], x, y)
+            got_bin = int(round(float(pts["orientation"][j]) / 11.25))
+            top2 = np.sort(hist)[-2:]
+            if abs(top2[1] - top2[0]) <= 1e-6 * top2[1]:
+                ties += 1  # the two leading bins agree to float rounding: either is a correct answer
+            else:
+                assert got_bin == int(np.argmax(hist)), f"octave {o} point ({x},{y}): bin {got_bin} vs {np.argmax(hist)}"
+            ref, d = _free_order_descriptor(oracle, mag, dirn, ow, oh, d16, x, y, pts["orientation"][j])
+            # a direction within float rounding of a bin border may fall either way: such samples move
+            # weight between neighbouring bins whatever the summation order, so they are set aside
+            frac = (np.where(d < 0, d + 360, d) % 360) / 45.0
+            if np.any(np.abs(frac - np.round(frac)) < 1e-4):
+                bin_edge += 1
+                continue
+            err = float(np.max(np.abs(ref - pts["data"][j].astype(np.float64))))
+            worst = max(worst, err)
+            assert err <= 1.0 / 512, f"octave {o} point ({x},{y}): descriptor off by {err}"
+            checked += 1
+        src = np.nan_to_num(oracle.downsample(blur[S], ow), nan=0.0)
+        ow = (ow + 1) // 2
+    print(f"order-free check: {checked} descriptors within {worst:.2e} of the double-precision histograms "
+          f"(bound 1/512 = {1 / 512:.2e}); {ties} orientation ties, {bin_edge} points with a sample on a bin border")
+    assert checked > 10
+
+
+def test_threshold_decisions_are_firm(oracle_mod, sift):
+    """cudaSiftD.cu:288-293: the edge and contrast decisions are float comparisons whose operands a
+    CUDA compiler may round differently (FMA contraction, pow width, division).  The oracle counts
+    the decisions within 1e-3 of their limits and those that change under such roundings."""
+    oracle = oracle_mod
+    cases = [("640x480 S=3 O=4 seed 1", dict(n_scales=3, n_octaves=4), sift.synth_image(640, 480, seed=1)),
+             ("1920x1080 S=2 O=5 seed 1000", dict(n_scales=2, n_octaves=5), sift.synth_image(1920, 1080, seed=1000)),
+             ("640x480 dense seed 6", dict(n_scales=2, n_octaves=4), sift.synth_image(640, 480, seed=6, dense=True))]
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "real_img1_crop.npz"))["gray"].astype(np.float32)
+    cases.append(("crop of Sift/img/img1.ppm", dict(n_scales=2, n_octaves=4), g))
+    for name, kw, img in cases:
+        pr = oracle.params(max_points=100000, **kw)
+        rep = oracle.ambiguity_report(pr, img, img.shape[1])
+        pts, _, total = oracle.extract(pr, img, img.shape[1])
+        print(name, rep)
+        assert rep["accepted"] == total == len(pts)
+        near = sum(v for k, v in rep.items() if "near" in k)
+        assert near <= max(2, total // 100), "threshold decisions near their limits should be rare"
+        assert rep["of_those_in_the_output"] <= max(1, total // 200)
