@@ -224,8 +224,24 @@ void sift_free_host(void *p);
 long sift_format_points(const SiftPoint *pts, int n, char *buf, long cap);
 /* sift.cu:144-163: writes <dst_dir>/<basename(src_path)>.sift.txt */
 int sift_save_points(const char *dst_dir, const char *src_path, const SiftPoint *pts, int n);
+/* The order the pipelines' writers put points in: scale, then row, then column (inside a group
+ * the reference's order is its atomic counter's, cudaSiftD.cu:296, and differs from run to run) */
+void sift_sort_points(SiftPoint *pts, int n);
 /* sift.cu:64-143: images two at a time on two streams and two counter slots */
 int sift(const char *dst_dir, const char **src_paths, int n_imgs);
+/* The same work for a whole list on several GPUs (sift.cu:68-134 treats its images as
+ * independent; nothing in the reference spans GPUs).  Image i goes to worker
+ * sift_list_partition(i, n_workers) = i mod n_workers; worker g is one host thread on device
+ * g mod sift_device_count() with its own stream and buffers, no data moves between GPUs, and
+ * the only gather is counts[] (n_imgs entries, optional), filled on the host in image order.
+ * Inside a worker file decoding, the GPU and the text writer overlap (batches of up to 32
+ * same-size images through sift_extract_batch_async on 8-bit pixels; an image of another size
+ * than its batch is done afterwards, alone).  dst_dir NULL: no files are written.  The files
+ * are byte for byte those of sift().  Host threads: SIFT_HOST_THREADS, else OMP_NUM_THREADS,
+ * else at most 16, shared out over the workers.  Returns 0 or -1. */
+int sift_extract_list_multi(const char *dst_dir, const char **src_paths, int n_imgs, int n_workers,
+                            int *counts);
+int sift_list_partition(int image, int n_workers);
 /* the reference hands count-1 to its writer (sift.cu:125); 1 reproduces that */
 void sift_pipeline_drop_last_point(int on);
 /* Visual check (image::drawPoint is declared at utils.h:32 and never defined):

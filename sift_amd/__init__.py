@@ -99,6 +99,9 @@ SYMBOLS = {
     "sift_format_points": (C.c_long, [_vp, C.c_int, C.c_char_p, C.c_long]),
     "sift_save_points": (C.c_int, [C.c_char_p, C.c_char_p, _vp, C.c_int]),
     "sift": (C.c_int, [C.c_char_p, C.POINTER(C.c_char_p), C.c_int]),
+    "sift_sort_points": (None, [_vp, C.c_int]),
+    "sift_extract_list_multi": (C.c_int, [C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int, _ip]),
+    "sift_list_partition": (C.c_int, [C.c_int, C.c_int]),
     "sift_draw_points": (C.c_int, [C.c_char_p, _fp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _fp]),
     "sift_pipeline_drop_last_point": (None, [C.c_int]),
     "sift_timing_enable": (None, [C.c_int]),
@@ -194,6 +197,18 @@ def load_pnm_gray(path):
         return np.ctypeslib.as_array(out, shape=(h.value, w.value)).copy()
     finally:
         lib().sift_free_host(out)
+
+
+def extract_list_multi(paths, dst_dir=None, n_workers=1):
+    """Every image file of `paths` on n_workers GPUs (image i on worker i mod n_workers); returns the
+    keypoint count per image, in list order.  Writes <dst_dir>/<name>.sift.txt when dst_dir is given."""
+    arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+    counts = np.zeros(len(paths), np.int32)
+    rc = lib().sift_extract_list_multi(os.fsencode(dst_dir) if dst_dir else None, arr, len(paths), n_workers,
+                                       counts.ctypes.data_as(_ip))
+    if rc:
+        raise SiftError(last_error() or "sift_extract_list_multi failed")
+    return counts
 
 
 def format_points(pts):

@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 static int g_drop_last = 0;
 
@@ -184,6 +185,25 @@ long sift_format_points(const SiftPoint *pts, int n, char *buf, long cap)
     return off;
 }
 
+/* Inside an (octave, scale) group the reference's points stand in the order its atomic
+ * counter handed out (cudaSiftD.cu:296), which is not a function of the input; two runs of it
+ * write different files.  The writers here put the points in one order: scale (groups
+ * ascend in scale, cudaSiftH.cu:94-95), then row, then column. */
+static int point_order(const void *a, const void *b)
+{
+    const SiftPoint *p = (const SiftPoint *)a, *q = (const SiftPoint *)b;
+    if (p->scale != q->scale) return p->scale < q->scale ? -1 : 1;
+    if (p->ypos != q->ypos) return p->ypos < q->ypos ? -1 : 1;
+    if (p->xpos != q->xpos) return p->xpos < q->xpos ? -1 : 1;
+    if (p->orientation != q->orientation) return p->orientation < q->orientation ? -1 : 1;
+    return 0;
+}
+
+void sift_sort_points(SiftPoint *pts, int n)
+{
+    if (pts && n > 1) qsort(pts, (size_t)n, sizeof(SiftPoint), point_order);
+}
+
 static int save_points_buf(const char *dst_dir, const char *src_path, const SiftPoint *pts, int n,
                            grow_buf *text)
 {
@@ -211,6 +231,14 @@ int sift_save_points(const char *dst_dir, const char *src_path, const SiftPoint 
     return rc;
 }
 
+/* the pipelines' writer: the points in their one order first (the buffer is the pipeline's own) */
+static int save_sorted(const char *dst_dir, const char *src_path, SiftPoint *pts, int n_all, int n_write,
+                       grow_buf *text)
+{
+    sift_sort_points(pts, n_all);
+    return save_points_buf(dst_dir, src_path, pts, n_write, text);
+}
+
 /* sift.cu:64-143: images are taken two at a time, each on its own stream and
  * counter slot; upload, extract, read back, write one text file per image.
  * Each image of a pair has its own host thread for the two host-side stages
@@ -229,7 +257,7 @@ typedef struct {
     void *stream;
     /* the current image */
     const char *path, *dst_dir;
-    int w, h, pitch, n, rc;
+    int w, h, pitch, n, n_all, rc;
 } lane_t;
 
 static void *lane_load(void *arg)
@@ -242,7 +270,7 @@ static void *lane_load(void *arg)
 static void *lane_save(void *arg)
 {
     lane_t *L = (lane_t *)arg;
-    L->rc = save_points_buf(L->dst_dir, L->path, (const SiftPoint *)L->h_pts.p, L->n, &L->text);
+    L->rc = save_sorted(L->dst_dir, L->path, (SiftPoint *)L->h_pts.p, L->n_all, L->n, &L->text);
     return NULL;
 }
 
@@ -310,6 +338,7 @@ int sift(const char *dst_dir, const char **src_paths, int n_imgs)
                 }
                 rc |= sift_memcpy_d2h_async(L[i].h_pts.p, L[i].d_pts, sizeof(SiftPoint) * (size_t)n, L[i].stream);
                 rc |= sift_stream_sync(L[i].stream);
+                L[i].n_all = n;
                 if (g_drop_last) n -= 1;
                 L[i].n = n < 0 ? 0 : n;
             }
@@ -384,5 +413,405 @@ int sift_draw_points(const char *path, const float *gray, int w, int pitch, int 
         fclose(f);
     }
     free(rgb);
+    return rc;
+}
+
+/* ---- the whole list on all GPUs -------------------------------------------------
+ * sift.cu:68-134 treats its images as independent (two at a time, no state shared between
+ * them but the counter slots).  Here the list is dealt over the GPUs, image i to worker
+ * i mod n_workers, one host thread per GPU with its own device, stream and buffers; no data
+ * moves between GPUs, and the only gather is the count array, filled in image order on the
+ * host.  Inside a worker the stages overlap: a pool of host threads decodes the files of
+ * batch j+1 into pinned memory and formats and writes the text of batch j-1 while the GPU
+ * holds batch j (one upload of 8-bit pixels, sift_extract_batch_async, one read-back of the
+ * counts, then only the points each image produced).  Output files are byte for byte those
+ * of sift(). */
+typedef struct {
+    void (*fn)(void *);
+    void *arg;
+    int *group; /* jobs of one group still to finish */
+} mt_job;
+
+typedef struct {
+    pthread_t *th;
+    int n_th;
+    mt_job *q;
+    int cap, head, count, stop;
+    pthread_mutex_t mu;
+    pthread_cond_t cv_job, cv_done;
+} mt_pool;
+
+static void *pool_main(void *arg)
+{
+    mt_pool *P = (mt_pool *)arg;
+    pthread_mutex_lock(&P->mu);
+    for (;;) {
+        while (!P->count && !P->stop) pthread_cond_wait(&P->cv_job, &P->mu);
+        if (!P->count && P->stop) break;
+        mt_job j = P->q[P->head];
+        P->head = (P->head + 1) % P->cap;
+        P->count--;
+        pthread_mutex_unlock(&P->mu);
+        j.fn(j.arg);
+        pthread_mutex_lock(&P->mu);
+        if (--*j.group == 0) pthread_cond_broadcast(&P->cv_done);
+    }
+    pthread_mutex_unlock(&P->mu);
+    return NULL;
+}
+
+static int pool_start(mt_pool *P, int n_th, int cap)
+{
+    memset(P, 0, sizeof *P);
+    pthread_mutex_init(&P->mu, NULL);
+    pthread_cond_init(&P->cv_job, NULL);
+    pthread_cond_init(&P->cv_done, NULL);
+    P->q = (mt_job *)calloc((size_t)cap, sizeof(mt_job));
+    P->th = (pthread_t *)calloc((size_t)n_th, sizeof(pthread_t));
+    P->cap = cap;
+    if (!P->q || !P->th) return -1;
+    for (int i = 0; i < n_th; ++i) {
+        if (pthread_create(&P->th[i], NULL, pool_main, P)) break;
+        P->n_th++;
+    }
+    return P->n_th > 0 ? 0 : -1;
+}
+
+/* the queue holds every job of the sets in flight: it cannot fill up */
+static void pool_submit(mt_pool *P, void (*fn)(void *), void *arg, int *group)
+{
+    pthread_mutex_lock(&P->mu);
+    ++*group;
+    P->q[(P->head + P->count) % P->cap] = (mt_job){fn, arg, group};
+    P->count++;
+    pthread_cond_signal(&P->cv_job);
+    pthread_mutex_unlock(&P->mu);
+}
+
+static void pool_wait(mt_pool *P, int *group)
+{
+    pthread_mutex_lock(&P->mu);
+    while (*group) pthread_cond_wait(&P->cv_done, &P->mu);
+    pthread_mutex_unlock(&P->mu);
+}
+
+static void pool_stop(mt_pool *P)
+{
+    pthread_mutex_lock(&P->mu);
+    P->stop = 1;
+    pthread_cond_broadcast(&P->cv_job);
+    pthread_mutex_unlock(&P->mu);
+    for (int i = 0; i < P->n_th; ++i) pthread_join(P->th[i], NULL);
+    free(P->th);
+    free(P->q);
+    pthread_mutex_destroy(&P->mu);
+    pthread_cond_destroy(&P->cv_job);
+    pthread_cond_destroy(&P->cv_done);
+}
+
+#define MT_SETS 3
+#define MT_MAX_BATCH 32
+
+struct mt_set;
+typedef struct {
+    struct mt_set *set;
+    int k;          /* position in the set */
+    int image;      /* index into the caller's list */
+    int status;     /* 0 decoded; 1 another geometry than the set's (done later, alone); < 0 error */
+    int n_points;
+    grow_buf text;
+} mt_item;
+
+typedef struct mt_set {
+    struct mt_worker *W;
+    int n, w, h;
+    grow_buf h_img, h_pts, h_counts; /* pinned */
+    unsigned char *d_img;
+    size_t d_img_cap;
+    SiftPoint *d_pts;
+    unsigned *d_counts;
+    int decode_left, format_left; /* job groups */
+    mt_item item[MT_MAX_BATCH];
+} mt_set;
+
+typedef struct mt_worker {
+    int index, n_workers, device, pool_threads, batch, cap;
+    const char *dst_dir;
+    const char **paths;
+    int n_imgs;
+    int *counts;
+    int rc;
+    pthread_t thread;
+    mt_pool pool;
+    void *stream;
+    mt_set set[MT_SETS];
+} mt_worker;
+
+/* header of a binary PGM/PPM: 0 and the geometry, or -1 */
+static int pnm_header(FILE *f, int *kind, int *w, int *h)
+{
+    if (fgetc(f) != 'P') return -1;
+    *kind = fgetc(f);
+    if (*kind != '5' && *kind != '6') return -1;
+    int maxv;
+    if (pnm_token(f, w) || pnm_token(f, h) || pnm_token(f, &maxv)) return -1;
+    return (*w < 1 || *h < 1 || maxv < 1 || maxv > 255) ? -1 : 0;
+}
+
+static int peek_geometry(const char *path, int *w, int *h)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return -1;
+    int kind;
+    const int rc = pnm_header(f, &kind, w, h);
+    fclose(f);
+    return rc;
+}
+
+/* one file into its place in the set's pinned 8-bit staging buffer; colour is reduced to grey as
+ * read_pnm_gray does (the grey values are integers, so the 8-bit entry gives the float entry's result) */
+static void decode_job(void *arg)
+{
+    mt_item *it = (mt_item *)arg;
+    mt_set *S = it->set;
+    const char *path = S->W->paths[it->image];
+    it->status = -1;
+    FILE *f = fopen(path, "rb");
+    if (!f) return;
+    int kind, w, h;
+    if (pnm_header(f, &kind, &w, &h) == 0) {
+        if (w != S->w || h != S->h) {
+            it->status = 1;
+        } else {
+            const size_t n = (size_t)w * h;
+            unsigned char *dst = (unsigned char *)S->h_img.p + n * (size_t)it->k;
+            if (kind == '5') {
+                if (fread(dst, 1, n, f) == n) it->status = 0;
+            } else {
+                unsigned char *rgb = (unsigned char *)malloc(3 * n);
+                if (rgb && fread(rgb, 1, 3 * n, f) == 3 * n) {
+                    for (size_t i = 0; i < n; ++i)
+                        dst[i] = (unsigned char)((1868 * rgb[3 * i + 2] + 9617 * rgb[3 * i + 1] + 4899 * rgb[3 * i] + 8192) >> 14);
+                    it->status = 0;
+                }
+                free(rgb);
+            }
+        }
+    }
+    fclose(f);
+}
+
+static void format_job(void *arg)
+{
+    mt_item *it = (mt_item *)arg;
+    mt_set *S = it->set;
+    mt_worker *W = S->W;
+    if (it->status) return;
+    if (W->counts) W->counts[it->image] = it->n_points;
+    if (!W->dst_dir) return;
+    int n = it->n_points - (g_drop_last ? 1 : 0);
+    if (n < 0) n = 0;
+    if (save_sorted(W->dst_dir, W->paths[it->image], (SiftPoint *)S->h_pts.p + (size_t)it->k * W->cap, it->n_points, n,
+                    &it->text))
+        it->status = -2;
+}
+
+/* buffers of a set for n images of w x h */
+static int set_prepare(mt_set *S, int n, int w, int h)
+{
+    mt_worker *W = S->W;
+    const size_t img = (size_t)w * h, need = img * (size_t)W->batch;
+    S->n = n;
+    S->w = w;
+    S->h = h;
+    S->h_img.pinned = S->h_pts.pinned = S->h_counts.pinned = 1;
+    if (grow(&S->h_img, need) || grow(&S->h_pts, sizeof(SiftPoint) * (size_t)W->cap * W->batch) ||
+        grow(&S->h_counts, sizeof(unsigned) * (size_t)W->batch))
+        return -1;
+    if (S->d_img_cap < need) {
+        if (S->d_img) sift_dev_free(S->d_img);
+        S->d_img = NULL;
+        S->d_img_cap = 0;
+        if (sift_dev_malloc((void **)&S->d_img, need)) return -1;
+        S->d_img_cap = need;
+    }
+    if (!S->d_pts && sift_dev_malloc((void **)&S->d_pts, sizeof(SiftPoint) * (size_t)W->cap * W->batch)) return -1;
+    if (!S->d_counts && sift_dev_malloc((void **)&S->d_counts, sizeof(unsigned) * (size_t)W->batch)) return -1;
+    return 0;
+}
+
+/* upload, extract, read back the counts, then the points each image produced */
+static int set_gpu(mt_set *S)
+{
+    mt_worker *W = S->W;
+    const size_t img = (size_t)S->w * S->h;
+    int any = 0;
+    for (int k = 0; k < S->n; ++k) any |= S->item[k].status == 0;
+    if (!any) return 0;
+    int rc = sift_memcpy_h2d_async(S->d_img, S->h_img.p, img * (size_t)S->n, W->stream);
+    if (!rc)
+        rc = sift_extract_batch_async(S->d_pts, NULL, S->d_counts, S->d_img, 1, (long)img, S->n, S->w, S->w, S->h, W->stream);
+    if (!rc) rc = sift_memcpy_d2h_async(S->h_counts.p, S->d_counts, sizeof(unsigned) * (size_t)S->n, W->stream);
+    if (!rc) rc = sift_stream_sync(W->stream);
+    const unsigned *cnt = (const unsigned *)S->h_counts.p;
+    for (int k = 0; k < S->n && !rc; ++k) {
+        mt_item *it = &S->item[k];
+        if (it->status) continue;
+        it->n_points = (int)cnt[k];
+        if (it->n_points > 0)
+            rc = sift_memcpy_d2h_async((SiftPoint *)S->h_pts.p + (size_t)k * W->cap, S->d_pts + (size_t)k * W->cap,
+                                       sizeof(SiftPoint) * (size_t)it->n_points, W->stream);
+    }
+    if (!rc) rc = sift_stream_sync(W->stream);
+    return rc;
+}
+
+static void *worker_main(void *arg)
+{
+    mt_worker *W = (mt_worker *)arg;
+    W->rc = -1;
+    if (sift_set_device(W->device)) return NULL;
+    if (sift_stream_create(&W->stream)) return NULL;
+    if (pool_start(&W->pool, W->pool_threads, 2 * MT_SETS * MT_MAX_BATCH + 8)) return NULL;
+    /* this worker's images, in list order */
+    int n_mine = 0;
+    for (int i = W->index; i < W->n_imgs; i += W->n_workers) ++n_mine;
+    int *mine = (int *)malloc(sizeof(int) * (size_t)(n_mine + 1));
+    int *later = (int *)malloc(sizeof(int) * (size_t)(n_mine + 1)); /* images of another size than their batch */
+    int n_later = 0, rc = (mine && later) ? 0 : -1;
+    for (int i = W->index, k = 0; rc == 0 && i < W->n_imgs; i += W->n_workers) mine[k++] = i;
+    for (int s = 0; s < MT_SETS; ++s) W->set[s].W = W;
+
+    /* pass 0: the list in batches; pass 1: what pass 0 set aside, one image at a time */
+    for (int pass = 0; pass < 2 && rc == 0; ++pass) {
+        const int *list = pass ? later : mine;
+        const int n_list = pass ? n_later : n_mine, B = pass ? 1 : W->batch;
+        const int nb = (n_list + B - 1) / B;
+        for (int j = 0; j <= nb && rc == 0; ++j) {
+            /* decoding of batch j starts once the set's previous use (batch j - MT_SETS) is written out */
+            if (j < nb) {
+                mt_set *S = &W->set[j % MT_SETS];
+                pool_wait(&W->pool, &S->format_left);
+                for (int k = 0; k < S->n; ++k)
+                    if (S->item[k].status < 0) rc = -1;
+                const int first = j * B, n = (n_list - first) < B ? (n_list - first) : B;
+                int w = 0, h = 0;
+                if (peek_geometry(W->paths[list[first]], &w, &h)) {
+                    fprintf(stderr, "Could not open or find the image %s\n", W->paths[list[first]]); /* utils.cc:15 */
+                    rc = -1;
+                    break;
+                }
+                if (set_prepare(S, n, w, h)) {
+                    rc = -1;
+                    break;
+                }
+                for (int k = 0; k < n; ++k) {
+                    mt_item *it = &S->item[k];
+                    it->set = S;
+                    it->k = k;
+                    it->image = list[first + k];
+                    it->n_points = 0;
+                    pool_submit(&W->pool, decode_job, it, &S->decode_left);
+                }
+            }
+            /* the GPU takes batch j - 1 while batch j is being decoded */
+            if (j >= 1) {
+                mt_set *S = &W->set[(j - 1) % MT_SETS];
+                pool_wait(&W->pool, &S->decode_left);
+                for (int k = 0; k < S->n; ++k) {
+                    if (S->item[k].status < 0) {
+                        fprintf(stderr, "Could not open or find the image %s\n", W->paths[S->item[k].image]);
+                        rc = -1;
+                    } else if (S->item[k].status == 1) {
+                        if (pass == 0) later[n_later++] = S->item[k].image;
+                        else rc = -1;
+                    }
+                }
+                if (rc == 0 && set_gpu(S)) rc = -1;
+                if (rc == 0)
+                    for (int k = 0; k < S->n; ++k) pool_submit(&W->pool, format_job, &S->item[k], &S->format_left);
+            }
+        }
+        for (int s = 0; s < MT_SETS; ++s) {
+            pool_wait(&W->pool, &W->set[s].decode_left);
+            pool_wait(&W->pool, &W->set[s].format_left);
+            for (int k = 0; k < W->set[s].n; ++k)
+                if (W->set[s].item[k].status < 0) rc = -1;
+            W->set[s].n = 0;
+        }
+    }
+    pool_stop(&W->pool);
+    for (int s = 0; s < MT_SETS; ++s) {
+        mt_set *S = &W->set[s];
+        release(&S->h_img);
+        release(&S->h_pts);
+        release(&S->h_counts);
+        if (S->d_img) sift_dev_free(S->d_img);
+        if (S->d_pts) sift_dev_free(S->d_pts);
+        if (S->d_counts) sift_dev_free(S->d_counts);
+        for (int k = 0; k < MT_MAX_BATCH; ++k) release(&S->item[k].text);
+    }
+    sift_stream_destroy(W->stream);
+    free(mine);
+    free(later);
+    W->rc = rc;
+    return NULL;
+}
+
+/* worker w of n_workers takes images w, w + n_workers, ...: which GPU an image goes to */
+int sift_list_partition(int image, int n_workers) { return n_workers > 0 ? image % n_workers : -1; }
+
+static int host_thread_budget(void)
+{
+    const char *e = getenv("SIFT_HOST_THREADS");
+    if (!e) e = getenv("OMP_NUM_THREADS");
+    int n = e ? atoi(e) : 0;
+    if (n < 1) {
+        const long on = sysconf(_SC_NPROCESSORS_ONLN);
+        n = on > 16 ? 16 : (int)on; /* a share of the machine, not all of it */
+    }
+    return n < 1 ? 1 : (n > 256 ? 256 : n);
+}
+
+int sift_extract_list_multi(const char *dst_dir, const char **src_paths, int n_imgs, int n_workers, int *counts)
+{
+    if (!src_paths || n_imgs < 0 || n_workers < 1 || n_workers > 64) return -1;
+    const int n_dev = sift_device_count();
+    if (n_dev < 1) return -1;
+    sift_params prm;
+    sift_get_params(&prm);
+    initDeviceConstant();
+    if (counts)
+        for (int i = 0; i < n_imgs; ++i) counts[i] = -1;
+    mt_worker *W = (mt_worker *)calloc((size_t)n_workers, sizeof(mt_worker));
+    if (!W) return -1;
+    int per = host_thread_budget() / n_workers;
+    if (per < 2) per = 2;
+    /* images per batch: the pinned read-back buffer of a set stays within 64 MB */
+    long batch = (64L << 20) / (long)(sizeof(SiftPoint) * (size_t)prm.max_points);
+    batch = batch < 1 ? 1 : (batch > MT_MAX_BATCH ? MT_MAX_BATCH : batch);
+    int started = 0, rc = 0;
+    for (int g = 0; g < n_workers; ++g) {
+        W[g].index = g;
+        W[g].n_workers = n_workers;
+        W[g].device = g % n_dev; /* more workers than GPUs share them in turn (rehearsals on one GPU) */
+        W[g].pool_threads = per;
+        W[g].batch = (int)batch;
+        W[g].cap = prm.max_points;
+        W[g].dst_dir = dst_dir;
+        W[g].paths = src_paths;
+        W[g].n_imgs = n_imgs;
+        W[g].counts = counts;
+        if (pthread_create(&W[g].thread, NULL, worker_main, &W[g])) {
+            rc = -1;
+            break;
+        }
+        ++started;
+    }
+    for (int g = 0; g < started; ++g) {
+        pthread_join(W[g].thread, NULL);
+        if (W[g].rc) rc = -1;
+    }
+    free(W);
     return rc;
 }

@@ -205,3 +205,13 @@ def test_draw_points_writes_a_ppm_with_marks(sift, oracle_mod, tmp_path):
     assert np.all((np.abs(d0 - 4.8) < 1.0) | (np.abs(d1 - 9.6) < 1.0)), "circles of radius 3*scale"
     untouched = ~(red | green)
     assert np.all(img[untouched] == 100)
+
+
+def test_list_partition_is_image_mod_workers(sift):
+    """Image i of a list goes to worker i mod n (BASELINE configs[3]); every image has exactly one worker."""
+    L = sift.lib()
+    for n in (1, 2, 4, 8):
+        owners = [L.sift_list_partition(i, n) for i in range(4096)]
+        assert owners == [i % n for i in range(4096)]
+        assert sorted(set(owners)) == list(range(n))
+    assert L.sift_list_partition(5, 0) == -1

@@ -442,8 +442,8 @@ def test_host_pipeline_writes_the_oracles_text_files(sift, oracle_mod, tmp_path)
             got = open(dst / (os.path.basename(p) + ".sift.txt")).read().splitlines()
             if drop:  # the reference hands its writer count - 1 (sift.cu:125)
                 assert len(got) == max(len(want) - 1, 0) and set(got) <= set(want)
-            else:
-                assert sorted(got) == sorted(want)
+            else:  # the writer's order is the oracle's canonical one: scale, row, column
+                assert got == oracle_mod.format_points(oracle_mod.sort_points(ref)).splitlines()
 
 
 def test_large_8k_image_against_oracle(sift, oracle_mod):
@@ -784,3 +784,44 @@ def test_slot_outlives_the_callers_stream(sift, oracle_mod):
         total += n
     acc, _ = sift.group_counts(slot)
     assert sum(acc) == n
+
+
+def test_list_pipeline_on_several_workers_matches_the_pairwise_pipeline(sift, oracle_mod, tmp_path):
+    """sift_extract_list_multi (image i on worker i mod n, one host thread per worker, decode /
+    GPU / writer overlapped) against sift() (the reference's pairwise loop, Sift/src/sift.cu:64-143):
+    the same files byte for byte, with 1 worker and with 2 and 3 workers sharing this box's GPU;
+    grey and colour files, two image sizes mixed in one list."""
+    import filecmp
+
+    pr = _params(sift, oracle_mod, n_scales=2, n_octaves=4, max_points=2500)
+    paths, ref_counts = [], []
+    for i in range(23):
+        w, h = (320, 200) if i % 5 != 3 else (256, 192)  # every fifth image has another size than its batch
+        g = sift.synth_image(w, h, seed=300 + i, dense=True).astype(np.uint8)
+        p = tmp_path / f"im{i:02d}.{'ppm' if i % 4 == 1 else 'pgm'}"
+        if i % 4 == 1:  # colour file whose grey value (Q14 weights) is g
+            rgb = np.repeat(g[:, :, None], 3, axis=2)
+            p.write_bytes(b"P6\n%d %d\n255\n" % (w, h) + rgb.tobytes())
+        else:
+            p.write_bytes(b"P5\n# comment\n%d %d\n255\n" % (w, h) + g.tobytes())
+        paths.append(str(p))
+        ref_counts.append(len(oracle_mod.extract(pr, g.astype(np.float32), w)[0]))
+    import ctypes as C
+
+    base = tmp_path / "pairwise"
+    base.mkdir()
+    arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+    assert sift.lib().sift(str(base).encode(), arr, len(paths)) == 0, sift.last_error()
+    for workers in (1, 2, 3):
+        out = tmp_path / f"multi{workers}"
+        out.mkdir()
+        counts = sift.extract_list_multi(paths, str(out), workers)
+        assert counts.tolist() == ref_counts
+        names = sorted(os.listdir(base))
+        assert names == sorted(os.listdir(out)) and len(names) == len(paths)
+        for f in names:
+            assert filecmp.cmp(base / f, out / f, shallow=False), f"{f} differs with {workers} workers"
+    # without a destination only the counts come back
+    assert sift.extract_list_multi(paths[:5], None, 2).tolist() == ref_counts[:5]
+    with pytest.raises(sift.SiftError):
+        sift.extract_list_multi(paths[:2] + [str(tmp_path / "missing.pgm")], None, 1)
