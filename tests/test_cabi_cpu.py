@@ -215,3 +215,21 @@ def test_list_partition_is_image_mod_workers(sift):
         assert owners == [i % n for i in range(4096)]
         assert sorted(set(owners)) == list(range(n))
     assert L.sift_list_partition(5, 0) == -1
+
+
+def test_host_code_and_oracle_under_address_and_ub_sanitizers():
+    """`make -C tests/asan run` (also `make -C oracle asan`, `make -C sift_amd/csrc asan`): the oracle
+    and the C host code (sift_host.c, pipeline.c against a CPU stand-in of the HIP layer) built with
+    -fsanitize=address,undefined and driven through arenas, slots, launch sets, loaders, the formatter
+    and both file pipelines.  CPU only."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-s", "-C", os.path.join(root, "tests", "asan"), "run"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "oracle driver finished" in r.stdout and "host driver finished" in r.stdout
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
