@@ -1737,6 +1737,10 @@ struct SiftPointD {
 };
 
 constexpr int REG = 23; // gradient region [x-11, x+11]: covers the rotated 16x16 patch
+#ifndef KP_RSTRIDE
+#define KP_RSTRIDE 23
+#endif
+constexpr int RSTRIDE = KP_RSTRIDE; // floats between rows of the region in LDS
 
 // The descriptor's rotated 16x16 samples read, through their bilinear corners,
 // only part of the 23x23 region, and which part depends on the orientation
@@ -1900,8 +1904,8 @@ __device__ __forceinline__ void region_patch(const float *bl, int w, int p, int 
         region_values<INTERIOR>(w, h, x, y, rx, ry, nb[q]);
         float m, d;
         grad_from(nb[q][0], nb[q][1], nb[q][2], nb[q][3], tab, m, d);
-        s_mag[ry * REG + rx] = m;
-        s_dir[ry * REG + rx] = d;
+        s_mag[ry * RSTRIDE + rx] = m;
+        s_dir[ry * RSTRIDE + rx] = d;
     }
 }
 
@@ -1920,8 +1924,8 @@ __device__ __forceinline__ void region_ring(const float *bl, int w, int p, int h
             region_values<INTERIOR>(w, h, x, y, rx, ry, nb);
             float m, d;
             grad_from(nb[0], nb[1], nb[2], nb[3], tab, m, d);
-            s_mag[e] = m;
-            s_dir[e] = d;
+            s_mag[ry * RSTRIDE + rx] = m;
+            s_dir[ry * RSTRIDE + rx] = d;
         }
     }
 }
@@ -1931,8 +1935,8 @@ __global__ __launch_bounds__(64) void keypoint_kernel(
     const unsigned *cand, const float4 *sub, long cand_stride, const unsigned *counts,
     long counts_stride, const unsigned *base_count, hl_keypoint_args a)
 {
-    __shared__ float s_mag[REG * REG + 3];
-    __shared__ float s_dir[REG * REG + 3];
+    __shared__ float s_mag[REG * RSTRIDE + 3];
+    __shared__ float s_dir[REG * RSTRIDE + 3];
     // partial sums: 32 lanes x 32 orientation bins (the two lane halves take turns),
     // later 64 lanes x 8 descriptor bins.  Kept small: the kernel runs as many waves as
     // its LDS allows, and it needs them to hide its memory round trips.
@@ -1983,7 +1987,7 @@ __global__ __launch_bounds__(64) void keypoint_kernel(
 #ifdef SIFT_POISON_REGION
         // test builds only: an entry that is read without having been computed for
         // this keypoint turns the descriptor into NaNs
-        for (int e = lane; e < REG * REG; e += 64) s_mag[e] = s_dir[e] = __builtin_nanf("");
+        for (int e = lane; e < REG * RSTRIDE; e += 64) s_mag[e] = s_dir[e] = __builtin_nanf("");
         __syncthreads();
 #endif
         // away from the border no address needs clamping and no value replacing
@@ -2003,7 +2007,7 @@ __global__ __launch_bounds__(64) void keypoint_kernel(
             const float wy = a.wnd[si * 16 + ty];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int e = (ty + 4) * REG + tx0 + k + 4;
+                const int e = (ty + 4) * RSTRIDE + tx0 + k + 4;
                 ow[k] = __fmul_rn(__fmul_rn(s_mag[e], a.wnd[si * 16 + tx0 + k]), wy);
                 ob[k] = assign_bin(s_dir[e], 11.25f);
             }
@@ -2017,9 +2021,11 @@ __global__ __launch_bounds__(64) void keypoint_kernel(
                 for (int q = 0; q < 5; ++q) reinterpret_cast<float4 *>(s_part)[lane + 64 * q] = float4{0.f, 0.f, 0.f, 0.f};
                 __syncthreads(); // the zeroes are in place
                 if ((lane >> 5) == half) {
+#ifndef KP_EXP_NO_ORI_SCATTER // (experiment switches: attribute the LDS bank conflicts; results are wrong with them)
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         s_part[(lane & 31) * OH_STRIDE + ob[k]] = oo[k]; // in order: the last write of a bin wins
+#endif
                 }
                 __syncthreads();
                 const float *col = s_part + (lane & 31);
@@ -2065,12 +2071,16 @@ __global__ __launch_bounds__(64) void keypoint_kernel(
                 // clamp-to-edge addressing needs no further clamping here
                 const int rx = min(max((int)fx - (x - 11), 0), REG - 2);
                 const int ry = min(max((int)fy - (y - 11), 0), REG - 2);
-                const int e = ry * REG + rx;
+#ifdef KP_EXP_NO_GATHER
+                const int e = lane + 0 * (rx + ry);
+#else
+                const int e = ry * RSTRIDE + rx;
+#endif
                 float val[2];
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const float *pl = c ? s_dir : s_mag;
-                    const float v00 = pl[e], v10 = pl[e + 1], v01 = pl[e + REG], v11 = pl[e + REG + 1];
+                    const float v00 = pl[e], v10 = pl[e + 1], v01 = pl[e + RSTRIDE], v11 = pl[e + RSTRIDE + 1];
                     const float top = __builtin_fmaf(ax, __fsub_rn(v10, v00), v00);
                     const float bot = __builtin_fmaf(ax, __fsub_rn(v11, v01), v01);
                     val[c] = __builtin_fmaf(ay, __fsub_rn(bot, top), top);
@@ -2083,8 +2093,10 @@ __global__ __launch_bounds__(64) void keypoint_kernel(
 #pragma unroll
             for (int q = 0; q < 3; ++q) reinterpret_cast<float4 *>(s_part)[lane + 64 * q] = float4{0.f, 0.f, 0.f, 0.f};
             __syncthreads();
+#ifndef KP_EXP_NO_DESC_SCATTER
 #pragma unroll
             for (int k = 0; k < 4; ++k) s_part[lane * DH_STRIDE + db[k]] = dout[k];
+#endif
         }
         __syncthreads();
         float hv[2];
