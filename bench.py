@@ -323,7 +323,7 @@ def main():
     if rank == 0:
         ab = algorithmic_bytes(S)
         px = sum(octave_pixels(2 * W, 2 * H, O + 1)) if args.upsample else sum(octave_pixels(W, H, O))
-        names = {"pyramid": sift_amd.K_PYRAMID, "alias": sift_amd.K_ALIAS, "verify": sift_amd.K_VERIFY,
+        names = {"pyramid": sift_amd.K_PYRAMID, "verify": sift_amd.K_VERIFY,
                  "detect": sift_amd.K_DETECT, "keypoint": sift_amd.K_KEYPOINT}
         kern = {}
         for name, kid in names.items():

@@ -260,7 +260,7 @@ enum {
     SIFT_K_KEYPOINT = 3,
     SIFT_K_PYRAMID = 4, /* fused row + column pass of the hot path */
     SIFT_K_VERIFY = 5,  /* sparse detector over queued contrast candidates */
-    SIFT_K_ALIAS = 6,   /* pre-filter of the rows the reference reads through aliased cells */
+    SIFT_K_ALIAS = 6,   /* unused (that pre-filter is part of the pyramid kernel now); keeps the numbering */
     SIFT_K_COUNT = 7
 };
 /* When enabled, every launch of the pyramid kernels is bracketed by events on

@@ -49,7 +49,6 @@ typedef struct {
     float sigma;        /* base sigma */
     float pix[HL_MAX_OCT]; /* input pixels per pixel of each octave (a power of two) */
     hl_octave oct[HL_MAX_OCT];
-    int band0[HL_MAX_OCT + 1];  /* first alias pre-filter unit of each octave (units: 32 rows x 256 columns) */
     int dense0[HL_MAX_OCT + 1]; /* first 96x32-pixel block of each octave (dense detector units) */
 } hl_detect_args;
 
@@ -122,27 +121,23 @@ int hl_col_blur_dog(const float *tmp, long tmp_stride, float *blur, long blur_st
  * (src_w x src_h) and is read at its even rows and columns, so w = ceil(src_w/2),
  * h = ceil(src_h/2).  p must be a multiple of 64: columns [w, p) of the
  * destination planes are written with don't-care values.
- * queue != NULL: pixels passing the detector's contrast and border tests (rows
- * with y mod 32 >= 30 excepted) are queued per scale: entry (x | y<<16) at
+ * queue != NULL: pixels passing the detector's contrast and border tests (where the
+ * reference reads the centre value through an aliased shared-memory cell, y mod 32 in
+ * {30, 31}: the value it reads) are queued per scale: entry (x | y<<16) at
  * queue[i*qcap + k], count in qcount[group0 + i]; a count above qcap means the
  * queue is incomplete and the dense detector must redo that scale.
  * plain != 0: every sample inside the border qualifies (profile "lowe"); 0: the
- * reference's tile rules apply (rows with y mod 32 >= 30 and middle tiles excepted). */
+ * reference's tile rules apply (middle tiles never fire, aliased centre cells). */
 int hl_pyramid(const void *src, int src_w, int src_h, int src_pitch, long src_stride, int src_mode,
                float *blur, long blur_stride, int w, int p, int h,
                int n_scales, int nimg, const hl_taps *taps, float contrast, unsigned *queue,
                long queue_stride, unsigned *qcount, long qcount_stride, int qcap, int group0,
                int plain, void *stream);
-/* The three detection launches cover every octave of the launch set.
- * hl_alias_prefilter: queues the pixels whose centre value the reference reads
- *   through an aliased shared-memory cell (y mod 32 in {30,31}).
+/* The detection launches cover every octave of the launch set.
  * hl_verify: rank + edge tests over the queues; accepted pixels are appended as
  *   (x | y<<16) to cand + group*cap, counted in counts[group].
  * hl_detect: the dense detector; with gate set (the queue counters) it only
  *   redoes the groups whose queue overflowed, with gate NULL it does everything. */
-int hl_alias_prefilter(const float *arena, long arena_stride, unsigned *queue, long queue_stride,
-                       unsigned *qcount, long qcount_stride, const hl_detect_args *a, int nimg,
-                       void *stream);
 int hl_verify(const float *arena, long arena_stride, const unsigned *queue, long queue_stride,
               const unsigned *qcount, long qcount_stride, unsigned *cand, long cand_stride,
               unsigned *counts, long counts_stride, const hl_detect_args *a, int nimg, void *stream);

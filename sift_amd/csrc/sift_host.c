@@ -454,7 +454,6 @@ static int enqueue_extract(slot_ctx *c, SiftPoint *pts, unsigned char *meta, con
         da.oct[oi].blur_off = c->blur_off[oi];
         da.oct[oi].queue_off = c->queue_off[oi];
         da.pix[oi] = pix;
-        da.band0[oi + 1] = da.band0[oi] + idivup(hh, 32) * idivup(ww, 256);
         da.dense0[oi + 1] = da.dense0[oi] + idivup(ww, 96) * idivup(hh, 32);
         unsigned *q = prefilter ? c->queue + c->queue_off[oi] : NULL;
         if (oi == 0 && up)
@@ -484,12 +483,9 @@ static int enqueue_extract(slot_ctx *c, SiftPoint *pts, unsigned char *meta, con
                            prefilter ? queued : NULL, COUNT_WORDS, &da, nimg, stream);
         if (r) return fail_hl(r, "dense detection");
     } else {
-        /* detection, once for all octaves: the pixels whose centre value the reference
-         * reads through an aliased cell join the queues, the queues are verified, and
-         * (only where a queue overflowed) a dense pass redoes the group */
+        /* detection, once for all octaves: the queues are verified, and (only where a
+         * queue overflowed) a dense pass redoes the group */
         if (prefilter) {
-            r = hl_alias_prefilter(A, AS, c->queue, c->queue_stride, queued, COUNT_WORDS, &da, nimg, stream);
-            if (r) return fail_hl(r, "aliased-row pre-filter");
             r = hl_verify(A, AS, c->queue, c->queue_stride, queued, COUNT_WORDS, c->cand, c->cand_stride,
                           c->counts, COUNT_WORDS, &da, nimg, stream);
             if (r) return fail_hl(r, "candidate verification");

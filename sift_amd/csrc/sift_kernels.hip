@@ -7,9 +7,9 @@
 // Kernels (reference counterpart in Sift/src/excludes/cudaSiftD.cu):
 //   pyramid_kernel          xblurMultiKernel :430-486 + yblurKernel :488-534 + resizeKernel
 //                           :544-559 in one pass, plus the contrast clause of
-//                           findExtremaKernel :293 as a pre-filter           [the hot path]
-//   alias_prefilter_kernel  the same clause for the pixels whose centre value the reference
-//                           reads through an aliased shared-memory cell :239-261
+//                           findExtremaKernel :293 as a pre-filter (the pixels whose centre
+//                           value the reference reads through an aliased shared-memory
+//                           cell :239-261 included)                          [the hot path]
 //   verify_kernel           findExtremaKernel :216-305 on the queued pixels
 //                           (+ hessianKernel :366-428 at candidates)
 //   detect_kernel           findExtremaKernel over every pixel (fall-back, and the whole
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     // plain: every column and row inside the border qualifies (the detector of the
     // "lowe" profile has no tiles)
     const bool pre_lane = xq > 8 && xq < w - 8 && (plain || xq_tile != 1);
-    const bool pre_lane0 = pre_lane && xq_tile == 0; // rows with y mod 32 = 30: see alias_prefilter_kernel
+    const bool pre_lane0 = pre_lane && xq_tile == 0; // rows with y mod 32 = 30: the right tile reads an aliased centre cell
     // the block is one wave: the fill of each list is a wave-uniform register, no
     // LDS atomic is needed to reserve slots
     unsigned lq_n[S];
@@ -404,15 +404,29 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     const unsigned long long pre_mask = __ballot(pre_lane), pre_mask0 = __ballot(pre_lane0);
 
     // appends the lanes of `hits` to the wave's list of scale i as pixels of row y
-    auto push = [&](const int i, const unsigned long long hits, const int y) __attribute__((always_inline)) {
+    // (dx: the queued pixel lies dx columns from the lane's own, see the aliased rows below)
+    auto push = [&](const int i, const unsigned long long hits, const int y, const int dx = 0) __attribute__((always_inline)) {
         if (hits) {
             // lanes below this one among the hits: the mask-bit-count instruction needs no per-lane mask register
             const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(hits >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hits, 0u));
             const unsigned slot = lq_n[i] + below;
-            if (((hits >> lane) & 1ull) && slot < PQ_CAP) lq[i][slot] = (unsigned)(x0 + lane) | ((unsigned)y << 16);
+            if (((hits >> lane) & 1ull) && slot < PQ_CAP) lq[i][slot] = (unsigned)(x0 + lane + dx) | ((unsigned)y << 16);
             lq_n[i] += (unsigned)__popcll(hits);
         }
     };
+    // Pixels whose centre value the reference reads through an aliased shared-memory cell.  For
+    // y mod 32 = 30 or 31 the centre cell of a pixel has been overwritten by the next DoG plane's
+    // tile (cudaSiftD.cu:239-261), i.e. it is DoG_{i+2} at a shifted position:
+    //   y mod 32 = 30, x mod 96 >= 64:  DoG_{i+2}[x-37, y-31]
+    //   y mod 32 = 31, x mod 96 <  32:  DoG_{i+2}[x+64, y-32]
+    //   y mod 32 = 31, x mod 96 >= 64:  DoG_{i+2}[x-37, y-31]
+    // Seen from the source side: rows 32b-1 and 32b of plane i+2 decide the contrast test of
+    // pixels 31 or 32 rows below and 37 columns to the right or 64 to the left.  The wave that
+    // completes such a row queues those targets.  alias_a / alias_b: lanes whose right / left
+    // target is a column the detector can accept.
+    const int xta = xq + 37, xtb = xq - 64;
+    const unsigned long long alias_a = __ballot(!plain && xq < w && (xta % XT_DATAX) >= 2 * XT_BDIM && xta > 8 && xta < w - 8);
+    const unsigned long long alias_b = __ballot(!plain && xq < w && xtb > 8 && (xtb % XT_DATAX) < XT_BDIM && xtb < w - 8);
     unsigned pend = 0u; // plain detector: this lane's candidates of the row above (see below)
 
     // One chunk of 20 input rows, straight line.  Input row r of the strip
@@ -498,7 +512,7 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
             // detector pre-filter: queue the pixels that pass the contrast test
             // (rare).  Pixels whose centre cell the reference reads through an
             // aliased shared-memory cell (y mod 32 = 31, and the right tile at
-            // y mod 32 = 30) are left to alias_prefilter_kernel.  No global memory
+            // y mod 32 = 30) are queued from their source rows, below.  No global memory
             // is touched here, so the counted waits of the row loop stay exact.
             const int yo = y0 + r - 2 * RADIUS;
             const bool row_ok = pre && valid && yo > 8 && yo < h - 8 && (plain || (yo & 31) < 31); // wave-uniform
@@ -508,6 +522,17 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
 #pragma unroll
                     for (int i = 0; i < S; ++i)
                         push(i, __ballot(fabsf(__fsub_rn(b[i + 1], b[i + 2])) > thr[i]) & lanes, yo);
+                }
+                const int ym = yo & 31;
+                if (pre && valid && (ym == 31 || ym == 0)) { // wave-uniform: a source row of the aliased cells
+                    const int yt = yo + 31;                 // target row with y mod 32 = 30 (from row 32b-1) or 31 (from row 32b)
+                    const bool yt_ok = yt > 8 && yt < h - 8, yt1_ok = yt + 1 > 8 && yt + 1 < h - 8;
+#pragma unroll
+                    for (int i = 0; i < S; ++i) {
+                        const unsigned long long big = __ballot(fabsf(__fsub_rn(b[i + 2], b[i + 3])) > thr[i]);
+                        if (yt_ok) push(i, big & alias_a, yt, 37);
+                        if (ym == 31 && yt1_ok) push(i, big & alias_b, yt + 1, -64);
+                    }
                 }
             } else if (pre) { // wave-uniform
                 // The plain detector wants a strict extremum over 26 neighbours.  Being one
@@ -775,81 +800,7 @@ __device__ __forceinline__ int find_octave(const int *unit0, int n_oct, int unit
     return o;
 }
 
-// Pre-filter for the rows pyramid_kernel leaves out.  In the reference the
-// centre value of a pixel with y mod 32 = 30 or 31 is read through a
-// shared-memory cell that the next DoG plane's tile has overwritten
-// (cudaSiftD.cu:239-261), i.e. it is DoG_{i+2} at a shifted position:
-//   y mod 32 = 30, x mod 96 >= 36:  DoG_{i+2}[x-37, y-31]
-//   y mod 32 = 31, x mod 96 <= 32:  DoG_{i+2}[x+64, y-32]
-//   y mod 32 = 31, x mod 96 >= 36:  DoG_{i+2}[x-37, y-31]
-// (elsewhere the pixel's own value, which pyramid_kernel has tested).  Seen
-// from the source side: rows yA = 32b-1 and yC = 32b of plane i+2 decide
-// the contrast test of pixels 31 or 32 rows below.  One wave reads those two
-// rows for 256 columns and queues the target pixels that pass.
-template <int S>
-__global__ __launch_bounds__(256) void alias_prefilter_kernel(const float *__restrict__ arena,
-                                                              long arena_stride, unsigned *queue,
-                                                              long queue_stride, unsigned *qcount,
-                                                              long qcount_stride, hl_detect_args a)
-{
-    const int lane = threadIdx.x & 63;
-    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (unit >= a.band0[a.n_oct]) return; // whole wave; no barrier in this kernel
-    const int oi = find_octave(a.band0, a.n_oct, unit);
-    const hl_octave oc = a.oct[oi];
-    const int w = oc.w, h = oc.h, p = oc.p;
-    // a unit is one band of 32 rows by 256 columns; an octave's units are numbered row-major
-    const int xchunks = (w + 255) / 256, u = unit - a.band0[oi];
-    const int xs4 = (u % xchunks) * 256 + 4 * lane;
-    const int yC = (u / xchunks) * 32, yA = yC - 1; // row 0 is a source row too (targets at y = 31)
-    const int z = blockIdx.z;
-    const long plane = (long)p * h;
-    const float *blur = arena + z * arena_stride + oc.blur_off;
-    queue += z * queue_stride + oc.queue_off;
-    qcount += z * qcount_stride + oi * S;
-    const bool in_x = xs4 < w;
-    // a queue that has overflowed belongs to the dense detector: nothing more is added
-    // (the test is folded into the hit so that the loads of all scales stay independent)
-    bool live[S];
-#pragma unroll
-    for (int i = 0; i < S; ++i) live[i] = qcount[i] <= (unsigned)oc.qcap;
-
-#pragma unroll
-    for (int i = 0; i < S; ++i) {
-        const float *src = blur + (i + 2) * plane; // DoG plane i+2 = blur plane i+2 - blur plane i+3
-        float va[4] = {0.f, 0.f, 0.f, 0.f}, vc[4] = {0.f, 0.f, 0.f, 0.f};
-        if (in_x && yA >= 0) {
-            const float4 t = *reinterpret_cast<const float4 *>(src + xs4 + (long)p * yA);
-            const float4 u = *reinterpret_cast<const float4 *>(src + plane + xs4 + (long)p * yA);
-            va[0] = __fsub_rn(t.x, u.x), va[1] = __fsub_rn(t.y, u.y), va[2] = __fsub_rn(t.z, u.z), va[3] = __fsub_rn(t.w, u.w);
-        }
-        if (in_x && yC < h) {
-            const float4 t = *reinterpret_cast<const float4 *>(src + xs4 + (long)p * yC);
-            const float4 u = *reinterpret_cast<const float4 *>(src + plane + xs4 + (long)p * yC);
-            vc[0] = __fsub_rn(t.x, u.x), vc[1] = __fsub_rn(t.y, u.y), vc[2] = __fsub_rn(t.z, u.z), vc[3] = __fsub_rn(t.w, u.w);
-        }
-        // up to three targets per source pixel: (a) and (b) from row yA, (c) from row yC
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int xs = xs4 + q;
-                const float v = t == 2 ? vc[q] : va[q];
-                const int xt = t == 1 ? xs - 64 : xs + 37;
-                const int yt = t == 0 ? yA + 31 : (t == 1 ? yA + 32 : yC + 31);
-                const int xm = xt % XT_DATAX;
-                const bool col_ok = t == 1 ? (xs >= 64 && xm < XT_BDIM) : (xm >= 2 * XT_BDIM);
-                const bool hit = live[i] && xs < w && col_ok && xt > 8 && xt < w - 8 && yt > 8 && yt < h - 8 &&
-                                 fabsf(v) > a.contrast;
-                append_hits(hit, (unsigned)xt | ((unsigned)yt << 16), lane, &qcount[i],
-                            queue + (long)i * oc.qcap, oc.qcap);
-            }
-        }
-    }
-}
-
-// Sparse detector: consumes the contrast candidates queued by pyramid_kernel
-// and alias_prefilter_kernel.  The queues of all (octave, scale) groups of an
+// Sparse detector: consumes the contrast candidates queued by pyramid_kernel.  The queues of all (octave, scale) groups of an
 // image form one list of 256-candidate items which the image's blocks
 // (gridDim.x of them) take in turn, so the launch has the same number of blocks
 // whatever the images hold and each block's share is even.  (A block per group
@@ -2583,23 +2534,6 @@ static int detect_args_ok(const hl_detect_args *a, int nimg)
         if ((c->blur_off & 3) || c->qcap < 1) return 0;
     }
     return 1;
-}
-
-int hl_alias_prefilter(const float *arena, long arena_stride, unsigned *queue, long queue_stride,
-                       unsigned *qcount, long qcount_stride, const hl_detect_args *a, int nimg,
-                       void *stream)
-{
-    if (!detect_args_ok(a, nimg) || (arena_stride & 3) || (((size_t)arena) & 15)) return -1001;
-    dim3 grid(idivup(a->band0[a->n_oct], 4), 1, nimg), block(256);
-    hipStream_t s = (hipStream_t)stream;
-    ScopedTimer t(6, s);
-    if (a->n_scales == 2)
-        hipLaunchKernelGGL((alias_prefilter_kernel<2>), grid, block, 0, s, arena, arena_stride, queue,
-                           queue_stride, qcount, qcount_stride, *a);
-    else
-        hipLaunchKernelGGL((alias_prefilter_kernel<3>), grid, block, 0, s, arena, arena_stride, queue,
-                           queue_stride, qcount, qcount_stride, *a);
-    return launch_status();
 }
 
 int hl_verify(const float *arena, long arena_stride, const unsigned *queue, long queue_stride,

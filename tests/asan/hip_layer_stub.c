@@ -146,12 +146,6 @@ static int args_ok(const hl_detect_args *a, int nimg)
 {
     return a && nimg > 0 && a->n_oct >= 1 && a->n_oct <= HL_MAX_OCT && a->cap >= 1;
 }
-int hl_alias_prefilter(const float *arena, long arena_stride, unsigned *queue, long queue_stride, unsigned *qcount,
-                       long qcount_stride, const hl_detect_args *a, int nimg, void *stream)
-{
-    (void)arena_stride, (void)queue, (void)queue_stride, (void)qcount, (void)qcount_stride, (void)stream;
-    return (arena && args_ok(a, nimg)) ? 0 : -1001;
-}
 int hl_verify(const float *arena, long arena_stride, const unsigned *queue, long queue_stride, const unsigned *qcount,
               long qcount_stride, unsigned *cand, long cand_stride, unsigned *counts, long counts_stride,
               const hl_detect_args *a, int nimg, void *stream)
