@@ -103,6 +103,55 @@ __global__ __launch_bounds__(64 * WAVES) void strips(float *__restrict__ out, co
     }
 }
 
+// 64 columns per wave as the pyramid kernel has them, but the stores of four rows go out together:
+// lane l writes 16 bytes, columns 4*(l%16).., of row y + l/16, so one instruction covers four
+// 256-byte row segments (what a transposition of four finished rows through LDS would allow).
+template <int NPL, int PF, int LDSB>
+__global__ __launch_bounds__(64) void strips_rows4(float *__restrict__ out, const float *__restrict__ in, int w, int p, int h,
+                                                   int rows, long out_stride, float a, float b)
+{
+    __shared__ float occ[LDSB / 4 + 1];
+    if (a == 12345.f) occ[threadIdx.x] = b;
+    if (a == 54321.f) out[0] = occ[threadIdx.x + 1];
+    int tx, ty, tz;
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y;
+        const unsigned nwg = gx * gy * gridDim.z;
+        const unsigned orig = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const unsigned q = nwg / 8, r = nwg % 8, xcd = orig % 8;
+        const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+        tx = (int)(t % gx);
+        ty = (int)((t / gx) % gy);
+        tz = (int)(t / (gx * gy));
+    }
+    const int lane = threadIdx.x;
+    const int x = tx * 64 + lane;
+    const int y0 = ty * rows, y1 = min(y0 + rows, h);
+    const float *s = in + tz * (long)p * h + x;
+    float *o = out + tz * out_stride + tx * 64 + (lane & 15) * 4;
+    const long plane = (long)p * h;
+    float g[PF];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) g[q] = s[(long)min(y0 + q, h - 1) * p];
+    for (int y = y0; y < y1; y += PF) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            v += g[q];
+            g[q] = s[(long)min(y + q + PF, h - 1) * p];
+        }
+#pragma unroll
+        for (int q4 = 0; q4 < PF; q4 += 4) {
+            const int yr = y + q4 + (lane >> 4);
+            if (yr < y1) {
+#pragma unroll
+                for (int i = 0; i < NPL; ++i)
+                    *reinterpret_cast<float4 *>(o + i * plane + (long)yr * p) = float4{v, v + a, v + b, v + (float)i};
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void flat_copy(float4 *out, const float4 *in, long n)
 {
     long i = blockIdx.x * 256L + threadIdx.x;
@@ -150,6 +199,19 @@ template <int VW, int WAVES, int LAYOUT, int FMAS, int PF, int LDSB = 0, int REM
     fflush(stdout);
 }
 
+template <int PF, int LDSB> static void run_rows4(int rows)
+{
+    const long plane = (long)P * H;
+    dim3 grid(W / 64, (H + rows - 1) / rows, NIMG);
+    const float ms = best_ms([&] {
+        hipLaunchKernelGGL((strips_rows4<NPL, PF, LDSB>), grid, dim3(64), 0, 0, g_out, g_in, W, P, H, rows, plane * NPL, 0.999f, 0.001f);
+    });
+    const double bytes = (double)plane * NIMG * 4 * (NPL + 1);
+    printf("64 columns per wave, stores of 4 rows per instruction, PF=%d rows=%4d lds=%5d: %7.3f ms  %5.2f TB/s  (%.1f us/image)\n", PF,
+           rows, LDSB, ms, bytes / ms / 1e9, ms * 1e3 / NIMG);
+    fflush(stdout);
+}
+
 int main()
 {
     const long plane = (long)P * H;
@@ -166,27 +228,11 @@ int main()
         ms = best_ms([&] { hipLaunchKernelGGL(flat_store, dim3(256 * 16), dim3(256), 0, 0, (float4 *)g_out, m); });
         printf("flat float4 store: %.3f ms  %.2f TB/s\n", ms, (double)m * 16 / ms / 1e9);
     }
-    // occupancy: 8 / 5 / 3 / 2 waves per SIMD (LDS per one-wave block caps the waves per CU)
     run<1, 1, 0, 0, 4>(540);
-    run<1, 1, 0, 0, 4, 8000>(540);
     run<1, 1, 0, 0, 4, 13000>(540);
-    run<1, 1, 0, 0, 4, 20000>(540);
-    run<1, 1, 0, 0, 8, 13000>(540);
-    run<1, 1, 0, 38, 4, 13000>(540);
-    run<1, 1, 0, 38, 8, 13000>(540);
-    run<2, 1, 0, 0, 4, 13000>(540);
+    run_rows4<4, 0>(540);
+    run_rows4<4, 13000>(540);
+    run_rows4<8, 13000>(540);
     run<4, 1, 0, 0, 4, 13000>(540);
-    run<4, 1, 0, 0, 4, 40000>(540);
-    // no XCD remap
-    run<1, 1, 0, 0, 4, 0, 0>(540);
-    run<1, 1, 0, 0, 4, 13000, 0>(540);
-    // planes interleaved row by row
-    run<1, 1, 2, 0, 4>(540);
-    run<1, 1, 2, 0, 4, 13000>(540);
-    run<4, 1, 2, 0, 4>(540);
-    run<1, 4, 2, 0, 4, 52000>(540);
-    // short strips
-    run<1, 1, 0, 0, 4, 13000>(60);
-    run<1, 1, 0, 0, 4, 13000>(1080);
     return 0;
 }
