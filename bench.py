@@ -76,12 +76,19 @@ def photo_density_rate(sift_amd, torch, steps=3, n=64):
     d_pts = torch.empty((n * CAP, sift_amd.POINT_FLOATS), dtype=torch.float32, device="cuda")
     _, counts = sift_amd.extract_batch(batch, W, d_pts=d_pts)
     torch.cuda.synchronize()
+    sift_amd.timing_reset()
+    sift_amd.timing_enable(True)
     t0 = time.perf_counter()
     for _ in range(steps):
         _, counts = sift_amd.extract_batch(batch, W, d_pts=d_pts)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    sift_amd.timing_enable(False)
+    kern = {name: sift_amd.timing_read(kid)[0] / (n * steps)
+            for name, kid in (("pyramid", sift_amd.K_PYRAMID), ("verify", sift_amd.K_VERIFY),
+                              ("detect", sift_amd.K_DETECT), ("keypoint", sift_amd.K_KEYPOINT))}
     return {"images_per_s": n * steps / dt, "keypoints_per_image": float(counts.mean()), "images": n,
+            "kernels_ms_per_image": kern,
             "source": "crop of Sift/img/img1.ppm tiled to 1920x1080 (tests/golden/real_img1_crop.npz)"}
 
 
@@ -152,8 +159,8 @@ def main():
     global S
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--chunk", type=int, default=0, help="images per launch set (0 = library default)")
     ap.add_argument("--lanes", type=int, default=0, help="launch sets in flight (0 = library default)")

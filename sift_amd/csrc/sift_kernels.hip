@@ -153,6 +153,14 @@ __global__ __launch_bounds__(256) void row_blur_kernel(const float *__restrict__
 // pixels of plane S as the next octave's base.
 // ---------------------------------------------------------------------------
 constexpr int COL_RING = 20;
+// waves per SIMD the fused pyramid kernel is compiled for (2 and 3 scales).  Measured on MI355X at
+// 2 scales: 2 waves 19.3 us per 1080p image, 3 waves 16.6, 4 waves (128 registers) 17.3.
+#ifndef PYR_WAVES_S2
+#define PYR_WAVES_S2 3
+#endif
+#ifndef PYR_WAVES_S3
+#define PYR_WAVES_S3 3
+#endif
 constexpr int COL_PF = 4;
 
 template <int S, bool STAGE>
@@ -270,7 +278,10 @@ constexpr int FZ_PF = 4;            // source rows in flight per wave
 constexpr int FZ_SLOTS = FZ_PF + 1; // LDS row buffers: the rows in flight and the row being read
 static_assert(20 % FZ_SLOTS == 0, "the row buffers must be used in whole turns per row chunk");
 constexpr int FZ_STAGE = 88; // floats staged per row
-constexpr int PQ_CAP = 1024; // contrast candidates one wave can hold per scale between flushes
+#ifndef PYR_PQ_CAP
+#define PYR_PQ_CAP 1024
+#endif
+constexpr int PQ_CAP = PYR_PQ_CAP; // contrast candidates one wave can hold per scale between flushes
 constexpr unsigned FZ_DROP = 0xfffffff0u; // per-lane buffer offset past every plane: the store is dropped
 
 // launch geometry of the reference's detector (cudaSiftH.cu:64-89): blocks of
@@ -283,7 +294,7 @@ constexpr int XT_WRITTEN = 98;
 constexpr int XT_PLANE_OFF = 3168;
 
 template <int S, int SRC_MODE, bool PLAIN>
-__global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
+__global__ __launch_bounds__(64, (S == 2 ? PYR_WAVES_S2 : PYR_WAVES_S3)) void pyramid_kernel(
     const float *__restrict__ src, int src_w, int src_h, int src_pitch, long src_stride,
     float *__restrict__ blur, long blur_stride, int w, int p, int h, int rows, hl_taps taps, float contrast, unsigned *__restrict__ queue,
     long queue_stride, unsigned *__restrict__ qcount, long qcount_stride, int qcap, int group0)
@@ -437,6 +448,7 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
             const int r = rb + rr;
             // keep each row's instructions together
             __builtin_amdgcn_sched_barrier(0);
+            if (r >= nin) return; // wave-uniform: the strip ended inside this chunk
             // row r + FZ_PF goes to the buffer row r - 1 was read from
             fetch((rr + FZ_PF) % FZ_SLOTS);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FZ_WAIT) : "memory"); // row r has landed
@@ -633,7 +645,7 @@ __global__ __launch_bounds__(64, (S == 2 ? 3 : 2)) void pyramid_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (PLAIN && pre && __ballot(pend != 0u)) { // the strip's last row has no row below in this wave
 #pragma unroll
-        for (int i = 0; i < S; ++i) push(i, __ballot(((pend >> i) | (pend >> (S + i))) & 1u), y0 + rb - 2 * RADIUS - 1);
+        for (int i = 0; i < S; ++i) push(i, __ballot(((pend >> i) | (pend >> (S + i))) & 1u), y1 - 1);
     }
     if (pre) flush();
 }
@@ -2256,16 +2268,16 @@ inline int idivup(int a, int b) { return (a + b - 1) / b; }
 
 int g_strip_override = 0; // > 0: rows per strip of the pyramid pass, for experiments
 
-// Rows per strip of the fused pyramid pass.  A wave walks its strip in chunks of 20 input
-// rows and needs 18 rows of apron, so a strip of r rows costs 20*ceil((r+18)/20) row steps;
-// the waves of a launch run in rounds of as many as the chip holds at once.  The strips are
-// cut (equal heights) so that rounds x steps per wave is smallest: tall strips when the batch
-// alone fills the chip (1080p, 256 images: 2 strips of 540 rows = 560 steps per column
-// instead of 6 x 200), short ones when a single image has to be spread over all SIMDs.
+// Rows per strip of the fused pyramid pass.  A wave walks its strip row by row and needs 18
+// rows of apron, so a strip of r rows costs r + 18 row steps; the waves of a launch run in
+// rounds of as many as the chip holds at once.  The strips are cut (equal heights) so that
+// rounds x steps per wave is smallest: tall strips when the batch alone fills the chip
+// (1080p, 256 images: 2 strips of 540 rows = 558 steps per column instead of 6 x 198),
+// short ones when a single image has to be spread over all SIMDs.
 int pyramid_strip_rows(int w, int h, int nimg, int n_scales)
 {
     if (g_strip_override > 0) return g_strip_override < h ? g_strip_override : h;
-    const long slots = 256L * 4 * (n_scales == 2 ? 3 : 2);
+    const long slots = 256L * 4 * (n_scales == 2 ? PYR_WAVES_S2 : PYR_WAVES_S3);
     const long gx = idivup(w, 64);
     long best_t = -1;
     int best_rows = h;
@@ -2274,7 +2286,7 @@ int pyramid_strip_rows(int w, int h, int nimg, int n_scales)
         if (rows < 2 && n > 1) break;
         if (n > 1 && rows == idivup(h, n - 1)) continue; // same strips as the last candidate
         const long strips = idivup(h, rows);
-        const long steps = idivup(rows + 2 * RADIUS, COL_RING);
+        const long steps = rows + 2 * RADIUS;
         const long rounds = (gx * strips * nimg + slots - 1) / slots;
         const long t = rounds * steps;
         if (best_t < 0 || t < best_t) best_t = t, best_rows = rows;
