@@ -168,9 +168,12 @@ int hl_upsample2x(const void *src, int src_u8, int src_pitch, long src_stride, f
                   long dst_stride, int w, int h, int nimg, void *stream);
 /* out[128*j + k] = min(255, round(512 * pts[j].data[k])) */
 int hl_quantize(const void *pts, int n, unsigned char *out, void *stream);
-/* base_count[z] = min(base_count[z] + sum(min(counts, cap)), cap) */
-int hl_finalize_counts(unsigned *base_count, const unsigned *counts, long counts_stride,
+/* base_count[z] = min(base_count[z] + sum(min(counts, cap)), cap); host_copy (pinned host memory
+ * or NULL) receives the same values */
+int hl_finalize_counts(unsigned *base_count, unsigned *host_copy, const unsigned *counts, long counts_stride,
                        int n_groups, int cap, int nimg, void *stream);
+/* a[0..na) = 0 and b[0..nb) = 0 in one launch (either range may be empty) */
+int hl_zero_words(unsigned *a, long na, unsigned *b, long nb, void *stream);
 
 /* dense stage kernels */
 int hl_subtract(float *dst, const float *a, const float *b, int w, int p, int h, void *stream);

@@ -70,6 +70,8 @@ static void *g_lane_stream[MAX_DEV][N_LANES];
 static void *g_lane_event[MAX_DEV][N_LANES + 1];
 static unsigned *g_batch_count[MAX_DEV];
 static int g_batch_count_n[MAX_DEV];
+static unsigned *g_host_count[MAX_DEV]; /* pinned host memory the device writes the counts to */
+static int g_host_count_n[MAX_DEV];
 static int g_lanes = N_LANES;
 static unsigned *g_slot_counter[MAX_DEV]; /* device, SIFT_MAX_SLOTS words */
 static int g_chunk = 256;
@@ -296,6 +298,11 @@ void sift_shutdown(void)
             g_batch_count[dev] = NULL;
             g_batch_count_n[dev] = 0;
         }
+        if (g_host_count[dev]) {
+            hl_host_free(g_host_count[dev]);
+            g_host_count[dev] = NULL;
+            g_host_count_n[dev] = 0;
+        }
         if (g_slot_counter[dev]) {
             hl_free(g_slot_counter[dev]);
             g_slot_counter[dev] = NULL;
@@ -415,11 +422,14 @@ static int ensure_arena(slot_ctx *c, int w, int h, int oct0, int nimg)
  * preplanned arena and nothing blocks. */
 static int enqueue_extract(slot_ctx *c, SiftPoint *pts, unsigned char *meta, const void *imgs,
                            int imgs_u8, long img_stride, int nimg, int pitch, int oct0,
-                           unsigned *base_count, void *stream)
+                           unsigned *base_count, int zero_base, unsigned *host_counts, void *stream)
 {
     const int S = g_params.n_scales, cap = g_params.max_points;
     const int lowe = c->profile == SIFT_PROFILE_LOWE, up = c->upsample, n_oct = c->n_oct;
-    int r = hl_memset_async(c->counts, 0, sizeof(unsigned) * COUNT_WORDS * nimg, stream);
+    /* the group counters start at zero; so do the point counts unless they carry on from an
+     * earlier call (extractSift, one call per octave) */
+    int r = hl_zero_words(c->counts, (long)COUNT_WORDS * nimg, zero_base ? base_count : NULL,
+                          zero_base ? nimg : 0, stream);
     if (r) return fail_hl(r, "resetting group counters");
     float *A = c->arena;
     const long AS = c->arena_stride;
@@ -515,7 +525,7 @@ static int enqueue_extract(slot_ctx *c, SiftPoint *pts, unsigned char *meta, con
     r = hl_keypoints(pts, cap, meta, A, AS, c->cand, lowe ? c->sub : NULL, c->cand_stride, c->counts,
                      COUNT_WORDS, base_count, &ka, nimg, stream);
     if (r) return fail_hl(r, "keypoint kernel");
-    r = hl_finalize_counts(base_count, c->counts, COUNT_WORDS, ka.n_groups, cap, nimg, stream);
+    r = hl_finalize_counts(base_count, host_counts, c->counts, COUNT_WORDS, ka.n_groups, cap, nimg, stream);
     if (r) return fail_hl(r, "count update");
     if (c->done) { /* (the entry that allocates nothing has no event: its caller orders by stream) */
         r = hl_event_record(c->done, stream);
@@ -587,7 +597,7 @@ void extractSift(SiftPoint *siftPt, float *d_src, int width, int pitch, int heig
         if (ensure_arena(c, width, height, octaveIdx, 1))
             break;
         enqueue_extract(c, siftPt, NULL, d_src, 0, 0, 1, pitch, octaveIdx,
-                        g_slot_counter[dev] + streamIdx, stream);
+                        g_slot_counter[dev] + streamIdx, 0, NULL, stream);
     } while (0);
     unlock_device(dev);
 }
@@ -747,12 +757,7 @@ int sift_extract_noalloc(SiftPoint *d_pts, unsigned *d_count, const float *d_img
         c.cand = (unsigned *)(b + off[3]);
         c.sub = bytes[4] ? (void *)(b + off[4]) : NULL;
         /* the list starts empty: the count is an output, not an accumulator as in extractSift */
-        r = hl_memset_async(d_count, 0, sizeof(unsigned), stream);
-        if (r) {
-            fail_hl(r, "sift_extract_noalloc: clearing the count");
-            break;
-        }
-        if (enqueue_extract(&c, d_pts, NULL, d_img, 0, 0, 1, pitch, 0, d_count, stream))
+        if (enqueue_extract(&c, d_pts, NULL, d_img, 0, 0, 1, pitch, 0, d_count, 1, NULL, stream))
             break;
         rc = 0;
     } while (0);
@@ -858,10 +863,26 @@ static int extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
             g_batch_count[dev] = (unsigned *)p;
             g_batch_count_n[dev] = n;
         }
+        if (h_counts && g_host_count_n[dev] < n) { /* pinned mirror of the counts, written by the device */
+            if (g_host_count[dev]) {
+                hl_device_sync();
+                hl_host_free(g_host_count[dev]);
+                g_host_count[dev] = NULL;
+                g_host_count_n[dev] = 0;
+            }
+            void *p = NULL;
+            int r = hl_host_alloc(&p, sizeof(unsigned) * (size_t)n);
+            if (r) {
+                fail_hl(r, "allocating the host copy of the batch counters");
+                break;
+            }
+            g_host_count[dev] = (unsigned *)p;
+            g_host_count_n[dev] = n;
+        }
         unsigned *bc = d_counts ? d_counts : g_batch_count[dev];
-        int r = hl_memset_async(bc, 0, sizeof(unsigned) * (size_t)n, stream);
+        unsigned *hc = h_counts ? g_host_count[dev] : NULL;
         /* fork: the private streams start after everything queued on the caller's stream */
-        if (!r) r = hl_event_record(g_lane_event[dev][N_LANES], stream);
+        int r = hl_event_record(g_lane_event[dev][N_LANES], stream);
         for (int l = 0; l < lanes && !r; ++l)
             r = hl_stream_wait_event(g_lane_stream[dev][l], g_lane_event[dev][N_LANES]);
         if (r) {
@@ -876,7 +897,8 @@ static int extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
             bad = enqueue_extract(&g_slots[dev][BATCH_SLOT + l], d_pts + (long)i0 * cap,
                                   d_meta ? d_meta + 2L * i0 * cap : NULL,
                                   (const char *)d_imgs + (long)i0 * img_stride * esz, imgs_u8,
-                                  img_stride, m, pitch, 0, bc + i0, g_lane_stream[dev][l]);
+                                  img_stride, m, pitch, 0, bc + i0, 1, hc ? hc + i0 : NULL,
+                                  g_lane_stream[dev][l]);
         }
         /* join: the caller's stream continues after both private streams */
         for (int l = 0; l < lanes; ++l) {
@@ -886,9 +908,9 @@ static int extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
         }
         if (bad)
             break;
-        if (!r && h_counts) {
-            r = hl_memcpy_async(h_counts, bc, sizeof(unsigned) * (size_t)n, 2, stream);
-            if (!r) r = hl_stream_sync(stream);
+        if (!r && h_counts) { /* the last kernel of every set wrote its counts to the pinned mirror */
+            r = hl_stream_sync(stream);
+            if (!r) memcpy(h_counts, hc, sizeof(unsigned) * (size_t)n);
         }
         if (r) {
             fail_hl(r, "finishing batch");

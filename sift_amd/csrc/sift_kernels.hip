@@ -2119,14 +2119,26 @@ __global__ __launch_bounds__(128) void quantize_kernel(const SiftPointD *pts, in
     out[128L * j + threadIdx.x] = (unsigned char)(q > 255.0f ? 255.0f : q);
 }
 
-__global__ void finalize_counts_kernel(unsigned *base_count, const unsigned *counts,
+__global__ void finalize_counts_kernel(unsigned *base_count, unsigned *host_copy, const unsigned *counts,
                                         long counts_stride, int n_groups, int cap, int nimg)
 {
     const int z = blockIdx.x * blockDim.x + threadIdx.x;
     if (z >= nimg) return;
     unsigned long long tot = base_count[z];
     for (int g = 0; g < n_groups; ++g) tot += min(counts[z * counts_stride + g], (unsigned)cap);
-    base_count[z] = (unsigned)min(tot, (unsigned long long)cap);
+    const unsigned v = (unsigned)min(tot, (unsigned long long)cap);
+    base_count[z] = v;
+    if (host_copy) host_copy[z] = v; // pinned host memory: there when the stream has drained
+}
+
+// zeroes two word ranges in one launch (the group counters of a launch set and its point counts)
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned *a, long na, unsigned *b, long nb)
+{
+    const long step = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += step) {
+        if (i < na) a[i] = 0u;
+        else b[i - na] = 0u;
+    }
 }
 
 // ---- dense stage kernels (one pixel per lane) -------------------------------
@@ -2692,11 +2704,21 @@ int hl_keypoints(void *pts, long pts_stride_points, unsigned char *meta, const f
     return launch_status();
 }
 
-int hl_finalize_counts(unsigned *base_count, const unsigned *counts, long counts_stride,
+int hl_finalize_counts(unsigned *base_count, unsigned *host_copy, const unsigned *counts, long counts_stride,
                        int n_groups, int cap, int nimg, void *stream)
 {
     hipLaunchKernelGGL(finalize_counts_kernel, dim3(idivup(nimg, 64)), dim3(64), 0,
-                       (hipStream_t)stream, base_count, counts, counts_stride, n_groups, cap, nimg);
+                       (hipStream_t)stream, base_count, host_copy, counts, counts_stride, n_groups, cap, nimg);
+    return launch_status();
+}
+
+int hl_zero_words(unsigned *a, long na, unsigned *b, long nb, void *stream)
+{
+    if (na < 0 || nb < 0 || (na > 0 && !a) || (nb > 0 && !b)) return -1001;
+    if (na + nb == 0) return 0;
+    const long blocks = (na + nb + 1023) / 1024; // four words per thread
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0,
+                       (hipStream_t)stream, a, na, b, nb);
     return launch_status();
 }
 

@@ -196,8 +196,16 @@ int hl_quantize(const void *pts, int n, unsigned char *out, void *stream)
     (void)stream;
     return (pts && out && n >= 0) ? 0 : -1001;
 }
-int hl_finalize_counts(unsigned *base_count, const unsigned *counts, long counts_stride, int n_groups, int cap, int nimg,
-                       void *stream)
+int hl_zero_words(unsigned *a, long na, unsigned *b, long nb, void *stream)
+{
+    (void)stream;
+    if (na < 0 || nb < 0 || (na > 0 && !a) || (nb > 0 && !b)) return -1001;
+    if (na) memset(a, 0, sizeof(unsigned) * (size_t)na);
+    if (nb) memset(b, 0, sizeof(unsigned) * (size_t)nb);
+    return 0;
+}
+int hl_finalize_counts(unsigned *base_count, unsigned *host_copy, const unsigned *counts, long counts_stride, int n_groups,
+                       int cap, int nimg, void *stream)
 {
     (void)stream;
     for (int z = 0; z < nimg; ++z) {
@@ -207,6 +215,7 @@ int hl_finalize_counts(unsigned *base_count, const unsigned *counts, long counts
             tot += c < (unsigned)cap ? c : (unsigned)cap;
         }
         base_count[z] = (unsigned)(tot < (unsigned long long)cap ? tot : (unsigned long long)cap);
+        if (host_copy) host_copy[z] = base_count[z];
     }
     return 0;
 }
