@@ -50,11 +50,13 @@ typedef struct {
     int busy; /* done has been recorded and not yet waited for */
 } slot_ctx;
 
-/* g_mu guards the parameters and tables; g_dev_mu[d] guards device d's slots, batch
+/* g_mu guards the building of the tables; g_dev_mu[d] guards device d's slots, batch
  * streams and counters.  Calls on different devices run side by side (one host
  * thread per GPU), calls on one device take turns because they share its arenas.
- * Parameters must not be changed while another thread extracts. */
+ * Every entry that reads the parameters holds g_params_rw for reading while it plans and
+ * enqueues; sift_set_params takes it for writing, so it waits for them and they for it. */
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_rwlock_t g_params_rw = PTHREAD_RWLOCK_INITIALIZER;
 static pthread_mutex_t g_dev_mu[MAX_DEV] = {[0 ... MAX_DEV - 1] = PTHREAD_MUTEX_INITIALIZER};
 static sift_params g_params = {4, 2, 2500, 1.6f, 10.0f, 10.0f, 0, 0};
 static int g_tables_ready = 0;
@@ -107,10 +109,15 @@ static int lock_device(const char *who)
         return -1;
     }
     pthread_mutex_lock(&g_dev_mu[dev]);
+    pthread_rwlock_rdlock(&g_params_rw);
     return dev;
 }
 
-static void unlock_device(int dev) { pthread_mutex_unlock(&g_dev_mu[dev]); }
+static void unlock_device(int dev)
+{
+    pthread_rwlock_unlock(&g_params_rw);
+    pthread_mutex_unlock(&g_dev_mu[dev]);
+}
 
 static int idivup(int a, int b) { return (a % b != 0) ? (a / b + 1) : (a / b); }      /* utils.cc:59 */
 static int ialignup(int A, int a) { return (A % a != 0) ? (A + a - A % a) : A; }     /* utils.cc:60 */
@@ -218,21 +225,30 @@ int sift_set_params(const sift_params *p)
         set_err("sigma and r_thresh must be positive");
         return -1;
     }
+    pthread_rwlock_wrlock(&g_params_rw);
     pthread_mutex_lock(&g_mu);
     g_params = *p;
     int r = build_tables();
     pthread_mutex_unlock(&g_mu);
+    pthread_rwlock_unlock(&g_params_rw);
     return r;
 }
 
-void sift_get_params(sift_params *p) { *p = g_params; }
+void sift_get_params(sift_params *p)
+{
+    pthread_rwlock_rdlock(&g_params_rw);
+    *p = g_params;
+    pthread_rwlock_unlock(&g_params_rw);
+}
 
 void sift_get_tables(float *blur, float *wnd, float *desc)
 {
+    pthread_rwlock_rdlock(&g_params_rw);
     tables_ok();
     memcpy(blur, g_blur, sizeof(float) * (g_params.n_scales + 3) * HL_TAPS);
     memcpy(wnd, g_wnd, sizeof(float) * g_params.n_scales * 16);
     memcpy(desc, g_desc, sizeof(float) * 16);
+    pthread_rwlock_unlock(&g_params_rw);
 }
 
 void sift_set_queue_cap(int n)
@@ -965,7 +981,7 @@ static int stage_ok(const char *name, const void *a, const void *b, int w, int p
     return 1;
 }
 
-void blurOctave(float *dst, float *src, int width, int pitch, int height, void *stream)
+static void blurOctave_held(float *dst, float *src, int width, int pitch, int height, void *stream)
 {
     if (!stage_ok("blurOctave", dst, src, width, pitch, height))
         return;
@@ -975,6 +991,15 @@ void blurOctave(float *dst, float *src, int width, int pitch, int height, void *
     }
     const int S = g_params.n_scales;
     const long plane = (long)pitch * height;
+    if ((pitch & 63) == 0 && plane * (S + 3) * 4 < 0xfffffff0L) {
+        /* the fused pass of the extraction path, without its candidate queues: the same planes
+         * bit for bit, nothing allocated and no wait */
+        int r = hl_pyramid(src, width, height, pitch, 0, 0, dst, 0, width, pitch, height, S, 1, &g_taps, 0.f,
+                           NULL, 0, NULL, 0, 0, 0, 0, stream);
+        if (r) fail_hl(r, "blurOctave");
+        return;
+    }
+    /* other pitches: row pass into scratch, column pass out of it (cudaSiftH.cu:218-258) */
     void *tmp = NULL;
     int r = hl_malloc(&tmp, sizeof(float) * (size_t)plane * (S + 3));
     if (r) {
@@ -992,7 +1017,7 @@ void blurOctave(float *dst, float *src, int width, int pitch, int height, void *
     hl_free(tmp);
 }
 
-void computeDiffOfGauss(float *dst, float *src, int width, int pitch, int height, void *stream)
+static void computeDiffOfGauss_held(float *dst, float *src, int width, int pitch, int height, void *stream)
 {
     if (!stage_ok("computeDiffOfGauss", dst, src, width, pitch, height))
         return;
@@ -1007,7 +1032,7 @@ void computeDiffOfGauss(float *dst, float *src, int width, int pitch, int height
     }
 }
 
-void computeHessian(float *dst, float *src, int width, int pitch, int height, void *stream)
+static void computeHessian_held(float *dst, float *src, int width, int pitch, int height, void *stream)
 {
     if (!stage_ok("computeHessian", dst, src, width, pitch, height))
         return;
@@ -1021,7 +1046,7 @@ void computeHessian(float *dst, float *src, int width, int pitch, int height, vo
     }
 }
 
-void computeGradient(float *dst, float *src, int width, int pitch, int height, void *stream)
+static void computeGradient_held(float *dst, float *src, int width, int pitch, int height, void *stream)
 {
     if (!stage_ok("computeGradient", dst, src, width, pitch, height))
         return;
@@ -1034,6 +1059,20 @@ void computeGradient(float *dst, float *src, int width, int pitch, int height, v
         }
     }
 }
+
+/* the stage entries read the parameters and tables: held for reading while they enqueue */
+#define STAGE_ENTRY(name)                                                                      \
+    void name(float *dst, float *src, int width, int pitch, int height, void *stream)         \
+    {                                                                                          \
+        pthread_rwlock_rdlock(&g_params_rw);                                                   \
+        name##_held(dst, src, width, pitch, height, stream);                                   \
+        pthread_rwlock_unlock(&g_params_rw);                                                   \
+    }
+STAGE_ENTRY(blurOctave)
+STAGE_ENTRY(computeDiffOfGauss)
+STAGE_ENTRY(computeHessian)
+STAGE_ENTRY(computeGradient)
+#undef STAGE_ENTRY
 
 void copyDeviceData(float *dst, float *src, int width, int pitch, int height, void *stream)
 {
