@@ -78,6 +78,16 @@ __global__ __launch_bounds__(64 * WAVES) void strips(float *__restrict__ out, co
                 if (LAYOUT == 0) {
 #pragma unroll
                     for (int i = 0; i < NPL; ++i) *reinterpret_cast<V *>(o + i * plane + (long)(y + q) * p + x) = pv[i];
+                } else if (LAYOUT == 3) { // tile-major: a 64*VW*WAVES-column tile's rows are contiguous, plane by plane
+                    const long tw = 64 * VW * WAVES;
+#pragma unroll
+                    for (int i = 0; i < NPL; ++i)
+                        *reinterpret_cast<V *>(o + i * plane + tx * tw * h + (long)(y + q) * tw + threadIdx.x * VW) = pv[i];
+                } else if (LAYOUT == 4) { // tile-major with the planes interleaved row by row: one stream per wave
+                    const long tw = 64 * VW * WAVES;
+#pragma unroll
+                    for (int i = 0; i < NPL; ++i)
+                        *reinterpret_cast<V *>(o + tx * tw * h * NPL + ((long)(y + q) * NPL + i) * tw + threadIdx.x * VW) = pv[i];
                 } else if (LAYOUT == 2) { // planes interleaved row by row
 #pragma unroll
                     for (int i = 0; i < NPL; ++i) *reinterpret_cast<V *>(o + ((long)(y + q) * NPL + i) * p + x) = pv[i];
@@ -195,7 +205,7 @@ template <int VW, int WAVES, int LAYOUT, int FMAS, int PF, int LDSB = 0, int REM
     });
     const double bytes = (double)plane * NIMG * 4 * (NPL + 1);
     printf("VW=%d waves/WG=%d layout=%s FMA/elem/plane=%3d PF=%d rows=%4d lds=%5d remap=%d: %7.3f ms  %5.2f TB/s  (%.1f us/image)\n", VW, WAVES,
-           LAYOUT == 0 ? "planar" : (LAYOUT == 1 ? "pixel " : "rowint"), FMAS, PF, rows, LDSB, REMAP, ms, bytes / ms / 1e9, ms * 1e3 / NIMG);
+           LAYOUT == 0 ? "planar" : (LAYOUT == 1 ? "pixel " : (LAYOUT == 2 ? "rowint" : (LAYOUT == 3 ? "tiled " : "tilint"))), FMAS, PF, rows, LDSB, REMAP, ms, bytes / ms / 1e9, ms * 1e3 / NIMG);
     fflush(stdout);
 }
 
@@ -228,11 +238,16 @@ int main()
         ms = best_ms([&] { hipLaunchKernelGGL(flat_store, dim3(256 * 16), dim3(256), 0, 0, (float4 *)g_out, m); });
         printf("flat float4 store: %.3f ms  %.2f TB/s\n", ms, (double)m * 16 / ms / 1e9);
     }
-    run<1, 1, 0, 0, 4>(540);
     run<1, 1, 0, 0, 4, 13000>(540);
-    run_rows4<4, 0>(540);
-    run_rows4<4, 13000>(540);
-    run_rows4<8, 13000>(540);
-    run<4, 1, 0, 0, 4, 13000>(540);
+    run<1, 1, 3, 0, 4, 13000>(540);
+    run<1, 1, 4, 0, 4, 13000>(540);
+    run<1, 1, 0, 38, 4, 13000>(540);
+    run<1, 1, 3, 38, 4, 13000>(540);
+    run<1, 1, 4, 38, 4, 13000>(540);
+    run<1, 1, 0, 0, 4>(540);
+    run<1, 1, 3, 0, 4>(540);
+    run<1, 1, 4, 0, 4>(540);
+    run<1, 1, 3, 0, 4, 13000>(180);
+    run<1, 1, 4, 0, 4, 13000>(180);
     return 0;
 }
