@@ -129,7 +129,10 @@ int sift_extract_batch_u8(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts
  * `stream` (work queued on it before the call is waited for; work queued on it
  * after the call sees the results).  imgs_u8 != 0: 8-bit images as above.  For
  * callers that keep the link and the GPU busy at the same time: upload batch
- * k+1 on a copy stream while batch k runs, read counts and points back later. */
+ * k+1 on a copy stream while batch k runs, read counts and points back later.
+ * Consecutive calls take the library's two private streams and arenas in turn:
+ * calls queued on different caller streams (with their own d_pts and d_counts)
+ * run side by side, calls on one stream follow each other. */
 int sift_extract_batch_async(SiftPoint *d_pts, unsigned char *d_meta, unsigned *d_counts,
                              const void *d_imgs, int imgs_u8, long img_stride, int n,
                              int width, int pitch, int height, void *stream);

@@ -75,6 +75,7 @@ static int g_batch_count_n[MAX_DEV];
 static unsigned *g_host_count[MAX_DEV]; /* pinned host memory the device writes the counts to */
 static int g_host_count_n[MAX_DEV];
 static int g_lanes = N_LANES;
+static int g_next_lane[MAX_DEV]; /* the lane the next non-blocking batch call starts on */
 static unsigned *g_slot_counter[MAX_DEV]; /* device, SIFT_MAX_SLOTS words */
 static int g_chunk = 256;
 static int g_queue_cap = QUEUE_CAP; /* 0: no pre-filter, dense detector only */
@@ -856,11 +857,17 @@ static int extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
         int chunk, n_sets;
         batch_sets(n, &chunk, &n_sets);
         const int lanes = n_sets < g_lanes ? n_sets : g_lanes;
+        /* A blocking call starts on the first lane.  Non-blocking calls take the lanes in turn,
+         * so that the short kernels at the end of one call run beside the long ones of the next
+         * (given that the caller queues them on different streams): each lane has its own
+         * arena, and calls that share a lane follow each other on its stream. */
+        const int lane0 = h_counts ? 0 : g_next_lane[dev] % g_lanes;
+        if (!h_counts) g_next_lane[dev] = (lane0 + n_sets) % g_lanes;
         if (ensure_lanes(dev))
             break;
         int bad = 0;
         for (int l = 0; l < lanes && !bad; ++l)
-            bad = ensure_arena(&g_slots[dev][BATCH_SLOT + l], width, height, 0, chunk);
+            bad = ensure_arena(&g_slots[dev][BATCH_SLOT + (lane0 + l) % g_lanes], width, height, 0, chunk);
         if (bad)
             break;
         if (!d_counts && g_batch_count_n[dev] < n) {
@@ -900,7 +907,7 @@ static int extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
         /* fork: the private streams start after everything queued on the caller's stream */
         int r = hl_event_record(g_lane_event[dev][N_LANES], stream);
         for (int l = 0; l < lanes && !r; ++l)
-            r = hl_stream_wait_event(g_lane_stream[dev][l], g_lane_event[dev][N_LANES]);
+            r = hl_stream_wait_event(g_lane_stream[dev][(lane0 + l) % g_lanes], g_lane_event[dev][N_LANES]);
         if (r) {
             fail_hl(r, "starting batch streams");
             break;
@@ -909,7 +916,7 @@ static int extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
         for (int k = 0; k < n_sets && !bad; ++k) {
             const int i0 = k * chunk;
             const int m = (n - i0) < chunk ? (n - i0) : chunk;
-            const int l = k % lanes;
+            const int l = (lane0 + k) % g_lanes;
             bad = enqueue_extract(&g_slots[dev][BATCH_SLOT + l], d_pts + (long)i0 * cap,
                                   d_meta ? d_meta + 2L * i0 * cap : NULL,
                                   (const char *)d_imgs + (long)i0 * img_stride * esz, imgs_u8,
@@ -917,7 +924,8 @@ static int extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
                                   g_lane_stream[dev][l]);
         }
         /* join: the caller's stream continues after both private streams */
-        for (int l = 0; l < lanes; ++l) {
+        for (int q = 0; q < lanes; ++q) {
+            const int l = (lane0 + q) % g_lanes;
             int r2 = hl_event_record(g_lane_event[dev][l], g_lane_stream[dev][l]);
             if (!r2) r2 = hl_stream_wait_event(stream, g_lane_event[dev][l]);
             if (r2 && !r) r = r2;

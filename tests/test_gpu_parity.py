@@ -695,6 +695,44 @@ def test_async_batch_entry_is_ordered_on_the_callers_stream(sift, oracle_mod):
     sift.set_params()
 
 
+def test_async_batches_in_flight_on_two_streams(sift, oracle_mod):
+    """Non-blocking batch calls take the library's private streams and arenas in turn, so calls
+    queued on different caller streams overlap on the device.  Five calls in flight (different
+    images, two sizes, launch sets of 4 so that a call of 6 images spans both lanes), no host
+    wait in between: each must equal the blocking entry's result for its images."""
+    sift.set_params(n_scales=2, n_octaves=4, max_points=1200)
+    sift.lib().sift_set_batch_chunk(4)
+    try:
+        cap = 1200
+        shapes = [(6, 320, 240), (3, 200, 264), (6, 320, 240), (4, 200, 264), (5, 320, 240)]
+        host = [np.stack([sift.synth_image(w, h, seed=7000 + 20 * b + i, dense=True) for i in range(n)])
+                for b, (n, w, h) in enumerate(shapes)]
+        want = []
+        for b, (n, w, h) in enumerate(shapes):
+            pts, counts = sift.extract_batch(torch.from_numpy(host[b]).cuda(), w)
+            want.append((pts.cpu().numpy().copy(), counts.copy()))
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        d_img = [torch.from_numpy(x).cuda() for x in host]
+        d_pts = [torch.full((n * cap, sift.POINT_FLOATS), float("nan"), dtype=torch.float32, device="cuda")
+                 for n, _, _ in shapes]
+        d_cnt = [torch.full((n,), -1, dtype=torch.int32, device="cuda") for n, _, _ in shapes]
+        torch.cuda.synchronize()
+        for b, (n, w, h) in enumerate(shapes):
+            sift.extract_batch_async(d_img[b], w, d_pts[b], d_cnt[b], stream=streams[b & 1])
+        torch.cuda.synchronize()
+        for b, (n, w, h) in enumerate(shapes):
+            counts = d_cnt[b].cpu().numpy()
+            assert np.array_equal(counts, want[b][1]), b
+            got = d_pts[b].cpu().numpy()
+            for i in range(n):
+                a = sift.points_to_numpy(torch.from_numpy(got), int(counts[i]), offset=i * cap)
+                r = sift.points_to_numpy(torch.from_numpy(want[b][0]), int(counts[i]), offset=i * cap)
+                assert oracle_mod.sort_points(a).tobytes() == oracle_mod.sort_points(r).tobytes(), (b, i)
+    finally:
+        sift.lib().sift_set_batch_chunk(256)
+        sift.set_params()
+
+
 def test_parameter_validation(sift):
     with pytest.raises(sift.SiftError):
         sift.set_params(profile=2)
