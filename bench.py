@@ -408,7 +408,7 @@ def main():
             out["roofline"]["copy_ceiling_GBps"] = ceil_gbps
             out["roofline"]["frac_of_copy_ceiling"] = achieved / 1e9 / ceil_gbps if ceil_gbps > 0 else None
         if world == 1 and not args.no_photo and not config4 and profile == 0 and S == 2 and not args.upsample:
-            out["photo_density"] = photo_density_rate(sift_amd, torch)
+            out["photo_density"] = photo_density_rate(sift_amd, torch, n=args.batch)
         if world == 1 and args.streaming and not config4:
             out["streaming"] = streaming_rate(sift_amd, torch, d_imgs, args.steps)
         if world == 1 and args.host_fed:
