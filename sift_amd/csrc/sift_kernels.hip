@@ -2592,8 +2592,11 @@ int hl_detect(const float *arena, long arena_stride, unsigned *cand, long cand_s
     // (a block walks over several pixel blocks also because one that has seen a group
     // reach the cap can drop the rest of its work)
     int gx = a->dense0[a->n_oct] < 4096 ? a->dense0[a->n_oct] : 4096;
-    int per_image = (gate ? 8192 : 16384) / nimg;
-    per_image = per_image < 32 ? 32 : (per_image > 1024 ? 1024 : per_image);
+    // (gated, 2048 blocks per launch measured best at 256 images of 1080p: 10 us instead of 22 for
+    // the launch that finds nothing to do, 6.8 instead of 7.3 us per image when every image needs it)
+    int per_image = (gate ? 2048 : 16384) / nimg;
+    const int least = gate ? 4 : 32;
+    per_image = per_image < least ? least : (per_image > 1024 ? 1024 : per_image);
     if (gx > per_image) gx = per_image;
     dim3 grid(gx, 1, nimg), block(DET_THREADS);
     // A cap of a few thousand points is normally reached inside the first group of an image
