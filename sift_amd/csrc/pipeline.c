@@ -672,7 +672,11 @@ static void *worker_main(void *arg)
     W->rc = -1;
     if (sift_set_device(W->device)) return NULL;
     if (sift_stream_create(&W->stream)) return NULL;
-    if (pool_start(&W->pool, W->pool_threads, 2 * MT_SETS * MT_MAX_BATCH + 8)) return NULL;
+    if (pool_start(&W->pool, W->pool_threads, 2 * MT_SETS * MT_MAX_BATCH + 8)) {
+        pool_stop(&W->pool); /* (joins whatever threads did start) */
+        sift_stream_destroy(W->stream);
+        return NULL;
+    }
     /* this worker's images, in list order */
     int n_mine = 0;
     for (int i = W->index; i < W->n_imgs; i += W->n_workers) ++n_mine;
