@@ -462,23 +462,15 @@ __global__ __launch_bounds__(64, (S == 2 ? PYR_WAVES_S2 : PYR_WAVES_S3)) void py
                 asm volatile("" ::: "memory");
             }
             float win[TAPS + 1]; // the 20th value only completes the last register pair
+            // the whole window at once: ten two-float reads in flight, the chains start as the first arrive
 #pragma unroll
-            for (int k = 0; k < 10; ++k) win[k] = lds[slot][lane + 3 + k];
+            for (int k = 0; k < TAPS + 1; ++k) win[k] = lds[slot][lane + 3 + k];
             float2v vp[NPAIR];
             float vs = 0.f;
 #pragma unroll
             for (int j = 0; j < NPAIR; ++j) vp[j] = float2v{0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < TAPS; ++k) {
-                if (k == 10) {
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int q = 10; q < TAPS + 1; ++q) win[q] = lds[slot][lane + 3 + q];
-                    // a packed operand names a register pair: without a defined partner the
-                    // last window value may share its pair with a load still in flight, and
-                    // the use would wait for all of memory
-                    asm volatile("" ::"v"(win[TAPS]));
-                }
                 const float2v wk = float2v{win[k], win[k]};
 #pragma unroll
                 for (int j = 0; j < NPAIR; ++j) vp[j] = pk_fma(tap2(taps, j, k), wk, vp[j]);
