@@ -101,6 +101,8 @@ int hl_copy_ceiling(size_t bytes, int repeats, double *gbps);
 
 /* timing */
 void hl_timing_enable(int on);
+/* on: launches of the calling thread are not timed even when timing is enabled (timing creates events) */
+void hl_timing_hold(int on);
 int hl_timing_read(int kernel, double *ms, long *launches);
 void hl_timing_reset(void);
 

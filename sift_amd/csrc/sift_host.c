@@ -773,8 +773,12 @@ int sift_extract_noalloc(SiftPoint *d_pts, unsigned *d_count, const float *d_img
         c.queue = (unsigned *)(b + off[2]);
         c.cand = (unsigned *)(b + off[3]);
         c.sub = bytes[4] ? (void *)(b + off[4]) : NULL;
-        /* the list starts empty: the count is an output, not an accumulator as in extractSift */
-        if (enqueue_extract(&c, d_pts, NULL, d_img, 0, 0, 1, pitch, 0, d_count, 1, NULL, stream))
+        /* the list starts empty: the count is an output, not an accumulator as in extractSift;
+         * the launches are never timed here (per-kernel timing creates events, which allocates) */
+        hl_timing_hold(1);
+        const int bad = enqueue_extract(&c, d_pts, NULL, d_img, 0, 0, 1, pitch, 0, d_count, 1, NULL, stream);
+        hl_timing_hold(0);
+        if (bad)
             break;
         rc = 0;
     } while (0);

@@ -2223,6 +2223,7 @@ struct TimedLaunch {
 };
 std::mutex g_tmu;
 bool g_timing = false;
+thread_local bool t_timing_held = false; // this thread's launches are not timed (timing creates events)
 std::vector<TimedLaunch> g_pending;
 double g_ms[8];
 long g_launches[8];
@@ -2232,7 +2233,7 @@ struct ScopedTimer {
     hipStream_t s;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     bool on;
-    ScopedTimer(int k, hipStream_t st) : kernel(k), s(st), on(g_timing)
+    ScopedTimer(int k, hipStream_t st) : kernel(k), s(st), on(g_timing && !t_timing_held)
     {
         if (on) {
             (void)hipEventCreate(&e0);
@@ -2370,6 +2371,7 @@ int hl_host_free(void *p) { return chk(hipHostFree(p)); }
 const char *hl_error_string(int code) { return hipGetErrorString((hipError_t)(-code)); }
 
 void hl_timing_enable(int on) { g_timing = on != 0; }
+void hl_timing_hold(int on) { t_timing_held = on != 0; }
 int hl_timing_read(int kernel, double *ms, long *launches)
 {
     drain_timers();

@@ -75,3 +75,21 @@ def test_no_alloc_entry_rejects_what_the_static_buffer_cannot_hold(sift):
     sift.lib().sift_clear_error()
     sift.set_params()
     assert rc == -1 and "static buffer holds" in msg and str(sift.lib().sift_noalloc_scratch_bytes()) in msg
+
+
+def test_no_alloc_entry_is_never_timed(sift, oracle_mod):
+    """Per-kernel timing records events, and creating an event allocates: with timing switched
+    on the entry still launches untimed (the timers see no launch) and gives the same points."""
+    sift.set_params(n_scales=2, n_octaves=3, max_points=2500)
+    img = sift.synth_image(320, 240, seed=504, dense=True)
+    want = _batch_entry(sift, img, 320)
+    sift.timing_reset()
+    sift.timing_enable(True)
+    try:
+        got = _noalloc(sift, img, 320)
+        launches = [sift.timing_read(k)[1] for k in (sift.K_PYRAMID, sift.K_VERIFY, sift.K_DETECT, sift.K_KEYPOINT)]
+    finally:
+        sift.timing_enable(False)
+    assert launches == [0, 0, 0, 0]
+    _same(oracle_mod, got, want)
+    sift.set_params()
