@@ -451,6 +451,7 @@ __global__ __launch_bounds__(64, (S == 2 ? PYR_WAVES_S2 : PYR_WAVES_S3)) void py
             if (r >= nin) return; // wave-uniform: the strip ended inside this chunk
             // row r + FZ_PF goes to the buffer row r - 1 was read from
             fetch((rr + FZ_PF) % FZ_SLOTS);
+            __builtin_amdgcn_s_setprio(0);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FZ_WAIT) : "memory"); // row r has landed
             constexpr int slot = rr % FZ_SLOTS;
             if (SRC_MODE == 1) { // integers to floats, in place (LDS operations of a wave stay in order)
@@ -508,6 +509,9 @@ __global__ __launch_bounds__(64, (S == 2 ? PYR_WAVES_S2 : PYR_WAVES_S3)) void py
                 b[2 * j + 1] = accp[j][e].y;
             }
             if (ODD) b[NP - 1] = accs[e];
+            // a wave that has a row to send goes first until its next fetch is out as well
+            // (measured: 0.8 % on the whole pass)
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < NP; ++i)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b[i]), bl_rs, vo,
