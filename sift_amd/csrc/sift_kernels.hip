@@ -2647,7 +2647,9 @@ int hl_detect_lowe(const float *arena, long arena_stride, unsigned *cand, void *
                    const hl_detect_args *a, int nimg, void *stream)
 {
     if (!detect_args_ok(a, nimg) || !sub) return -1001;
-    const int gx = gate ? 32 : (a->dense0[a->n_oct] < 4096 ? a->dense0[a->n_oct] : 4096);
+    // (gated: about 2048 blocks per launch, as for the reference-profile detector)
+    const int gated = 2048 / nimg < 4 ? 4 : (2048 / nimg > 32 ? 32 : 2048 / nimg);
+    const int gx = gate ? gated : (a->dense0[a->n_oct] < 4096 ? a->dense0[a->n_oct] : 4096);
     dim3 grid(gx, 1, nimg), block(256);
     hipStream_t s = (hipStream_t)stream;
     ScopedTimer t(2, s);
