@@ -20,7 +20,14 @@ What each file pins:
                                  (400x300, 2 scales, 3 + 1 octaves, seed 3): an anchor against the
                                  build's own definition drifting; nothing in the reference defines it.
 
-`python tests/golden/make_golden.py lowe` rewrites only the last one.
+  config1_images.npz             the reference's three sample images at full size as 8-bit grey
+                                 (Sift/img/img1.ppm, img2.ppm: 800x640; img3.ppm: 1024x575; grey =
+                                 image::imload's weights, which Sift/result/result.ppm pins for
+                                 img3): inputs of the configuration the reference itself runs
+                                 (2 scales, 4 octaves, cap 2500).  Data only; expected points come
+                                 from the oracle at test time.
+
+`python tests/golden/make_golden.py lowe` rewrites only the lowe fixture, `... config1` only the images.
 """
 import hashlib
 import os
@@ -57,10 +64,25 @@ def lowe_fixture():
     print("lowe 400x300 up-sampled keypoints:", len(pts))
 
 
+def config1_fixture():
+    out = {}
+    for k, name in ((1, "img1"), (2, "img2"), (3, "img3")):
+        g = oracle.gray_q14(read_pnm(os.path.join(REF, "img", name + ".ppm")))
+        out[f"gray{k}"] = g.astype(np.uint8)
+    res = read_pnm(os.path.join(REF, "result/result.ppm"))[..., 0]
+    assert np.array_equal(out["gray3"], res)  # the reference's own grey version of img3
+    np.savez_compressed(os.path.join(HERE, "config1_images.npz"), **out)
+    print("config 1 images:", {k: v.shape for k, v in out.items()})
+
+
 def main():
     if sys.argv[1:] == ["lowe"]:
         lowe_fixture()
         return
+    if sys.argv[1:] == ["config1"]:
+        config1_fixture()
+        return
+    config1_fixture()
     lowe_fixture()
     for S in (2, 3):
         pr = oracle.params(n_scales=S)

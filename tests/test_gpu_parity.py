@@ -111,6 +111,35 @@ def test_real_image_crop_against_committed_golden(sift, oracle_mod):
     assert oracle_mod.sort_points(got.view(oracle_mod.POINT_DTYPE)).tobytes() == z["points"].tobytes()
 
 
+@pytest.mark.parametrize("key", ["gray1", "gray2", "gray3"])
+def test_reference_sample_images_at_full_size(sift, oracle_mod, key):
+    """The configuration the reference itself runs (Sift/src/utils.h:4-19: 2 scales, 4 octaves, cap
+    2500) on its own three sample images at full size (Sift/img/img1.ppm, img2.ppm, img3.ppm,
+    committed as 8-bit grey data).  With a cap that holds everything the points equal the oracle's
+    as sets, bit for bit, through the single-image, the batch and the 8-bit batch entries; at the
+    reference's cap, which the two 800x640 photographs exceed, the output is a cap-sized subset of
+    that list."""
+    g8 = np.load(os.path.join(GOLD, "config1_images.npz"))[key]
+    g = g8.astype(np.float32)
+    h, w = g.shape
+    big = 60000
+    pr = _params(sift, oracle_mod, n_scales=2, n_octaves=4, max_points=big)
+    ref, _, total = oracle_mod.extract(pr, g, w)
+    assert 600 < total == len(ref) < big
+    want = oracle_mod.sort_points(ref).tobytes()
+    got = _extract_gpu(sift, g, w)
+    assert oracle_mod.sort_points(got.view(oracle_mod.POINT_DTYPE)).tobytes() == want
+    for stack in (g[None], g8[None]):
+        pts, counts = sift.extract_batch(torch.from_numpy(np.ascontiguousarray(stack)).cuda(), w)
+        got = sift.points_to_numpy(pts, int(counts[0])).view(oracle_mod.POINT_DTYPE)
+        assert oracle_mod.sort_points(got).tobytes() == want
+    _params(sift, oracle_mod, n_scales=2, n_octaves=4, max_points=2500)
+    got = _extract_gpu(sift, g, w).view(oracle_mod.POINT_DTYPE)
+    have = {r.tobytes() for r in ref}
+    assert len(got) == min(2500, total) and all(r.tobytes() in have for r in got)
+    sift.set_params()
+
+
 def test_lowe_against_committed_golden(sift, oracle_mod):
     """Profile "lowe" with the doubled first octave against the committed fixture: refined
     points and their 8-bit descriptors, byte for byte."""

@@ -242,6 +242,26 @@ def test_real_image_crop_golden(oracle_mod):
     assert oracle_mod.sort_points(pts).tobytes() == z["points"].tobytes()
 
 
+def test_config1_images_are_the_references_own(oracle_mod):
+    """The committed full-size grey images of the reference's configuration: img3's equals the
+    reference's known-answer file (Sift/result/result.ppm, pinned by its checksum beside the crop),
+    and the oracle's counts for the reference's configuration are what they were when the fixture
+    was made (2724 and 2853 points, above the cap of 2500, in the two 800x640 images; 629 in img3)."""
+    import hashlib
+
+    z = np.load(os.path.join(GOLD, "config1_images.npz"))
+    crop = np.load(os.path.join(GOLD, "gray_img3_crop.npz"))
+    assert z["gray1"].shape == z["gray2"].shape == (640, 800) and z["gray3"].shape == (575, 1024)
+    assert hashlib.sha256(z["gray3"].tobytes()).hexdigest() == str(crop["full_gray_sha256"])
+    assert np.array_equal(z["gray3"][200:264, 400:496], crop["gray"])
+    for key, n_all in (("gray1", 2724), ("gray2", 2853), ("gray3", 629)):
+        g = z[key].astype(np.float32)
+        pts, _, total = oracle_mod.extract(oracle_mod.params(n_scales=2, n_octaves=4, max_points=60000), g, g.shape[1])
+        assert len(pts) == total == n_all
+        capped, _, _ = oracle_mod.extract(oracle_mod.params(n_scales=2, n_octaves=4, max_points=2500), g, g.shape[1])
+        assert len(capped) == min(n_all, 2500)
+
+
 def test_cap_and_octave0_argument(oracle_mod, sift):
     img = sift.synth_image(640, 480, seed=6, dense=True)
     full, meta, total = oracle_mod.extract(oracle_mod.params(max_points=20000), img, 640)
