@@ -9,7 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-static int g_dev = 0;
+static __thread int g_dev = 0; /* the current device belongs to the calling thread, as in HIP */
 int hl_device_count(void) { return 2; } /* two pretend devices: the per-device paths get exercised */
 int hl_set_device(int dev)
 {

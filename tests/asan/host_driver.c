@@ -48,6 +48,19 @@ static void *device_thread(void *arg)
     return NULL;
 }
 
+/* rewrites the (unchanged) parameters and reads them back while the device threads extract:
+ * writers and readers of the parameters meet on the parameter lock */
+static void *params_thread(void *arg)
+{
+    (void)arg;
+    for (int rep = 0; rep < 200; ++rep) {
+        sift_params p;
+        sift_get_params(&p);
+        CHECK(sift_set_params(&p) == 0);
+    }
+    return NULL;
+}
+
 int main(int argc, char **argv)
 {
     const char *tmp = argc > 1 ? argv[1] : "/tmp";
@@ -258,9 +271,10 @@ int main(int argc, char **argv)
     CHECK(sift_list_partition(13, 4) == 1);
 
     /* two host threads, one per pretend device */
-    pthread_t th[2];
+    pthread_t th[3];
     for (intptr_t d = 0; d < 2; ++d) pthread_create(&th[d], NULL, device_thread, (void *)d);
-    for (int d = 0; d < 2; ++d) pthread_join(th[d], NULL);
+    pthread_create(&th[2], NULL, params_thread, NULL);
+    for (int d = 0; d < 3; ++d) pthread_join(th[d], NULL);
 
     double gbps;
     CHECK(sift_measure_copy_ceiling(1 << 20, 1, &gbps) == 0);

@@ -233,3 +233,21 @@ def test_host_code_and_oracle_under_address_and_ub_sanitizers():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "oracle driver finished" in r.stdout and "host driver finished" in r.stdout
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
+
+
+def test_host_code_under_thread_sanitizer():
+    """`make -C tests/asan tsan`: the same host driver (two device threads, the list pipeline's
+    workers and job pool, the per-device locks and the parameter lock) under -fsanitize=thread."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-s", "-C", os.path.join(root, "tests", "asan"), "tsan"], capture_output=True, text=True,
+                       timeout=600)
+    if "unexpected memory mapping" in r.stderr:  # (the sanitizer's runtime refuses some kernels' address-space layouts)
+        pytest.skip("ThreadSanitizer cannot run on this machine")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "host driver finished" in r.stdout
+    assert "WARNING: ThreadSanitizer" not in r.stderr
