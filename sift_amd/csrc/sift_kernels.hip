@@ -681,11 +681,6 @@ __device__ __forceinline__ float tile_read(const float *b3, long plane, int w, i
     return in ? v : 0.f;
 }
 
-__device__ __forceinline__ float center_value(const float *b3, long plane, int w, int p, int h, int x, int y)
-{
-    return tile_read(b3, plane, w, p, h, x / XT_DATAX, y >> 5, 1, 1 + x % XT_DATAX, 1 + (y & 31));
-}
-
 struct __attribute__((packed, aligned(4))) float3u {
     float a, b, c;
 };
