@@ -278,6 +278,13 @@ constexpr int FZ_PF = 3;            // source rows in flight per wave (measured:
 constexpr int FZ_SLOTS = FZ_PF + 1; // LDS row buffers: the rows in flight and the row being read
 static_assert(20 % FZ_SLOTS == 0, "the row buffers must be used in whole turns per row chunk");
 constexpr int FZ_STAGE = 88; // floats staged per row
+// Cache policy of the plane stores: non-temporal, device scope (the "nt" and "sc1" bits).  The planes
+// stream out and are read again only by later kernels; kept out of the way, they leave L2 to the
+// source lines neighbouring column tiles share.  Measured: the pass 1.3 % faster, and the verifier,
+// which runs after it, 20 % faster.
+#ifndef FZ_STORE_POLICY
+#define FZ_STORE_POLICY 18
+#endif
 #ifndef PYR_PQ_CAP
 #define PYR_PQ_CAP 1024
 #endif
@@ -515,7 +522,7 @@ __global__ __launch_bounds__(64, (S == 2 ? PYR_WAVES_S2 : PYR_WAVES_S3)) void py
 #pragma unroll
             for (int i = 0; i < NP; ++i)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b[i]), bl_rs, vo,
-                                                      (int)(out_row + i * plane_b), 0);
+                                                      (int)(out_row + i * plane_b), FZ_STORE_POLICY);
             out_row += valid ? (unsigned)p * 4u : 0u;
             // detector pre-filter: queue the pixels that pass the contrast test
             // (rare).  Pixels whose centre cell the reference reads through an
