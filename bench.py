@@ -13,11 +13,18 @@ on rank i mod N, every rank's share resident in its HBM and worked through in ba
 256; `value` is 4096 divided by the slowest rank's time (strong scaling) and rank 0
 gathers the per-image keypoint counts in image order.
 
+Started bare with `--gpus N` for N > 1 (no WORLD_SIZE in the environment) the program
+starts its own N ranks, one process per GPU, before anything in it has touched a GPU, relays
+rank 0's line and exits non-zero if any rank failed.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -49,6 +56,40 @@ def algorithmic_bytes(s):
     readers; the next octave reads blur plane S in place).
     `detect`: the dense detector reads the S+3 blur planes."""
     return {"pyramid": (1 + (s + 3)) * 4.0, "detect": (s + 3) * 4.0}
+
+
+def source_hash():
+    """Hash of the sources that decide what the pyramid kernel moves; tools/pmc_summary.py stores
+    it beside the counted traffic so that a figure counted on other code is not reported."""
+    h = hashlib.sha256()
+    for rel in ("sift_amd/csrc/sift_kernels.hip", "sift_amd/csrc/sift_host.c"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def spawn_ranks(n):
+    """One child process per GPU, this same command line, rendezvous on 127.0.0.1.  The parent has
+    not imported torch or the library: nothing here has initialised a GPU.  Returns the exit code."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    share = max(1, host_threads() // n)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS=str(share))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
 
 
 def host_threads():
@@ -213,6 +254,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=256)
     args = ap.parse_args()
     S = args.scales
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     import sift_amd
@@ -397,9 +441,12 @@ def main():
             try:
                 t = json.load(open(tf)).get(kernel_names[dom])
                 if t and t.get("batch") == args.batch and not config4:
-                    out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = ("rocprofv3 FETCH_SIZE (x2) and WRITE_SIZE passes over this "
-                                                         "command, profiles/pmc_traffic.json")
+                    if t.get("source_hash") == source_hash():
+                        out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                        out["roofline"]["traffic_source"] = ("rocprofv3 FETCH_SIZE (x2) and WRITE_SIZE passes over this "
+                                                             "command on these kernel sources, profiles/pmc_traffic.json")
+                    else:  # counted on other kernel sources than the ones in this tree
+                        out["roofline"]["traffic_source"] = "stale"
             except (ValueError, OSError):
                 pass
         # what this GPU's memory system gives a kernel that only moves bytes, measured in this run

@@ -62,7 +62,9 @@ typedef struct {
  * travel to the kernels as launch arguments, so there is nothing to upload). */
 void initDeviceConstant(void);
 /* cudaSiftH.cu:120-127 -- zeroes the point counter of every stream slot on
- * the current device (synchronous, like the reference's symbol copy). */
+ * the current device.  Waits for work the slots still have in flight (the
+ * reference's symbol copy follows all earlier work); getPointCount reads zero
+ * from then on, and the slot's next extractSift starts its list at zero. */
 void initDeviceVariables(void);
 /* cudaSiftH.cu:9-60 -- one image: octaves octaveIdx..n_octaves-1, appending
  * keypoints with orientation and descriptor to siftPt (device array of
@@ -73,7 +75,8 @@ void initDeviceVariables(void);
 void extractSift(SiftPoint *siftPt, float *d_src, int width, int pitch, int height,
                  void *stream, int streamIdx, int octaveIdx);
 /* cudaSiftH.cu:323-328 -- waits for the slot's work, returns its point count
- * (clamped to max_points), or -1 on error. */
+ * (clamped to max_points), or -1 on error.  The count arrives in pinned host
+ * memory with the slot's last kernel: one event wait, no copy. */
 int getPointCount(int streamIdx);
 
 /* ---- stage launchers (Sift/src/cudaSiftH.h:17-20), dense planes -----------
@@ -103,6 +106,10 @@ void sift_get_params(sift_params *p);
  * cudaSiftD.h:16-25). */
 const char *sift_last_error(void);
 void sift_clear_error(void);
+/* Makes msg the calling thread's last error: how a thread that ran library calls on
+ * behalf of another hands its message over (sift_extract_list_multi does so for its
+ * worker threads). */
+void sift_set_last_error(const char *msg);
 /* tap tables as the kernels receive them: blur[(S+3)*19], wnd[S*16], desc[16] */
 void sift_get_tables(float *blur, float *wnd, float *desc);
 /* frees every arena on the current device */
@@ -202,6 +209,7 @@ void sift_set_batch_lanes(int n);
  * cudaImage.cu:23-68, sift.cu:30-61, and the stream calls in sift.cu:94-130) */
 int sift_device_count(void);
 int sift_set_device(int dev);
+int sift_get_device(void); /* the calling thread's current device, or -1 */
 int sift_dev_malloc(void **p, size_t bytes);
 int sift_dev_malloc_pitch(float **p, int *pitch_floats, int width, int height);
 int sift_dev_free(void *p);
@@ -216,6 +224,11 @@ int sift_stream_destroy(void *stream);
 int sift_stream_sync(void *stream);
 int sift_host_alloc_pinned(void **p, size_t bytes);
 int sift_host_free_pinned(void *p);
+/* 8-bit grey pixels on the device to the float image extractSift takes (the convertTo(CV_32F)
+ * of image::imload, utils.cc:13, done after the upload instead of before it: a quarter of the
+ * bytes cross the link).  Pitches in elements.  Asynchronous on `stream`. */
+int sift_convert_u8_f32(float *d_dst, int dst_pitch, const unsigned char *d_src, int src_pitch,
+                        int width, int height, void *stream);
 
 /* ---- host pipeline (counterpart of Sift/src/sift.cu:64-163, utils.cc:8-17) ---
  * Binary PGM/PPM -> float grey image (malloc'ed; release with sift_free_host).

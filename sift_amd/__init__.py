@@ -64,6 +64,7 @@ SYMBOLS = {
     "sift_get_params": (None, [C.POINTER(Params)]),
     "sift_last_error": (C.c_char_p, []),
     "sift_clear_error": (None, []),
+    "sift_set_last_error": (None, [C.c_char_p]),
     "sift_get_tables": (None, [_fp, _fp, _fp]),
     "sift_shutdown": (None, []),
     "sift_extract_batch": (C.c_int, [_vp, _vp, _ip, _vp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
@@ -82,6 +83,7 @@ SYMBOLS = {
     "sift_set_strip_rows": (None, [C.c_int]),
     "sift_device_count": (C.c_int, []),
     "sift_set_device": (C.c_int, [C.c_int]),
+    "sift_get_device": (C.c_int, []),
     "sift_dev_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
     "sift_dev_malloc_pitch": (C.c_int, [C.POINTER(_vp), _ip, C.c_int, C.c_int]),
     "sift_dev_free": (C.c_int, [_vp]),
@@ -94,6 +96,7 @@ SYMBOLS = {
     "sift_stream_sync": (C.c_int, [_vp]),
     "sift_host_alloc_pinned": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
     "sift_host_free_pinned": (C.c_int, [_vp]),
+    "sift_convert_u8_f32": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "sift_load_pnm_gray": (C.c_int, [C.c_char_p, C.POINTER(_fp), _ip, _ip]),
     "sift_free_host": (None, [_vp]),
     "sift_format_points": (C.c_long, [_vp, C.c_int, C.c_char_p, C.c_long]),

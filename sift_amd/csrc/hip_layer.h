@@ -182,6 +182,8 @@ int hl_subtract(float *dst, const float *a, const float *b, int w, int p, int h,
 int hl_hessian(float *dst, const float *src, int w, int p, int h, void *stream);
 int hl_gradient(float *dst, const float *src, int w, int p, int h, void *stream);
 int hl_copy(float *dst, const float *src, int w, int p, int h, void *stream);
+/* 8-bit pixels to floats on the device (pitches in elements) */
+int hl_u8_to_f32(float *dst, int dp, const unsigned char *src, int sp, int w, int h, void *stream);
 
 #ifdef __cplusplus
 }

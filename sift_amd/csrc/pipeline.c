@@ -239,128 +239,6 @@ static int save_sorted(const char *dst_dir, const char *src_path, SiftPoint *pts
     return save_points_buf(dst_dir, src_path, pts, n_write, text);
 }
 
-/* sift.cu:64-143: images are taken two at a time, each on its own stream and
- * counter slot; upload, extract, read back, write one text file per image.
- * Each image of a pair has its own host thread for the two host-side stages
- * (decode before, format and write after the extraction), and the buffers are kept
- * from pair to pair: the reference allocates and frees everything per pair, and its host
- * stages take a hundred times longer than the extraction here.  Unlike the reference
- * the writer runs before the buffers are released and every point is written (the
- * reference passes count-1, sift.cu:125; call sift_pipeline_drop_last_point(1) to
- * reproduce that). */
-typedef struct {
-    /* kept from pair to pair */
-    grow_buf raw, img, text, h_pts; /* img and h_pts are pinned */
-    float *d_img;
-    size_t d_img_floats;
-    SiftPoint *d_pts;
-    void *stream;
-    /* the current image */
-    const char *path, *dst_dir;
-    int w, h, pitch, n, n_all, rc;
-} lane_t;
-
-static void *lane_load(void *arg)
-{
-    lane_t *L = (lane_t *)arg;
-    L->rc = read_pnm_gray(L->path, &L->raw, &L->img, &L->w, &L->h);
-    return NULL;
-}
-
-static void *lane_save(void *arg)
-{
-    lane_t *L = (lane_t *)arg;
-    L->rc = save_sorted(L->dst_dir, L->path, (SiftPoint *)L->h_pts.p, L->n_all, L->n, &L->text);
-    return NULL;
-}
-
-/* runs fn for the nq lanes, the second on a thread of its own */
-static void run_lanes(lane_t *L, int nq, void *(*fn)(void *))
-{
-    pthread_t th;
-    int threaded = 0;
-    if (nq > 1) threaded = pthread_create(&th, NULL, fn, &L[1]) == 0;
-    fn(&L[0]);
-    if (nq > 1) {
-        if (threaded) pthread_join(th, NULL);
-        else fn(&L[1]);
-    }
-}
-
-int sift(const char *dst_dir, const char **src_paths, int n_imgs)
-{
-    sift_params prm;
-    sift_get_params(&prm);
-    lane_t L[2];
-    memset(L, 0, sizeof L);
-    for (int i = 0; i < 2; ++i) L[i].img.pinned = L[i].h_pts.pinned = 1;
-    const size_t pts_bytes = sizeof(SiftPoint) * (size_t)prm.max_points;
-    int done = 0, rc = 0;
-    while (done < n_imgs && rc == 0) {
-        const int nq = (n_imgs - done > 1) ? 2 : 1;
-        for (int i = 0; i < nq; ++i) {
-            L[i].path = src_paths[done + i];
-            L[i].dst_dir = dst_dir;
-        }
-        run_lanes(L, nq, lane_load);
-        for (int i = 0; i < nq && rc == 0; ++i) {
-            if (L[i].rc) {
-                fprintf(stderr, "Could not open or find the image %s\n", L[i].path);
-                rc = -1;
-                break;
-            }
-            const size_t need = (size_t)L[i].w * L[i].h;
-            if (L[i].d_img_floats < need) {
-                if (L[i].d_img) sift_dev_free(L[i].d_img);
-                L[i].d_img = NULL;
-                L[i].d_img_floats = 0;
-                rc |= sift_dev_malloc((void **)&L[i].d_img, need * sizeof(float));
-                if (!rc) L[i].d_img_floats = need;
-            }
-            L[i].pitch = L[i].w;
-            if (!L[i].d_pts) rc |= sift_dev_malloc((void **)&L[i].d_pts, pts_bytes);
-            if (grow(&L[i].h_pts, pts_bytes)) rc = -1;
-            if (!L[i].stream) rc |= sift_stream_create(&L[i].stream);
-        }
-        if (rc == 0) {
-            initDeviceConstant();
-            initDeviceVariables();
-            for (int i = 0; i < nq; ++i)
-                rc |= sift_memcpy2d_h2d_async(L[i].d_img, L[i].pitch, (const float *)L[i].img.p, L[i].w,
-                                              L[i].w, L[i].h, L[i].stream);
-            for (int i = 0; i < nq; ++i)
-                extractSift(L[i].d_pts, L[i].d_img, L[i].w, L[i].pitch, L[i].h, L[i].stream, i, 0);
-            for (int i = 0; i < nq && rc == 0; ++i) {
-                int n = getPointCount(i);
-                if (n < 0) {
-                    rc = -1;
-                    break;
-                }
-                rc |= sift_memcpy_d2h_async(L[i].h_pts.p, L[i].d_pts, sizeof(SiftPoint) * (size_t)n, L[i].stream);
-                rc |= sift_stream_sync(L[i].stream);
-                L[i].n_all = n;
-                if (g_drop_last) n -= 1;
-                L[i].n = n < 0 ? 0 : n;
-            }
-            if (rc == 0) {
-                run_lanes(L, nq, lane_save);
-                for (int i = 0; i < nq; ++i) rc |= L[i].rc;
-            }
-        }
-        done += nq;
-    }
-    for (int i = 0; i < 2; ++i) {
-        if (L[i].stream) sift_stream_destroy(L[i].stream);
-        if (L[i].d_img) sift_dev_free(L[i].d_img);
-        if (L[i].d_pts) sift_dev_free(L[i].d_pts);
-        release(&L[i].raw);
-        release(&L[i].img);
-        release(&L[i].text);
-        release(&L[i].h_pts);
-    }
-    return rc;
-}
-
 /* ---- visualisation ------------------------------------------------------------
  * The reference declares image::drawPoint (utils.h:32) and never defines it.
  * Keypoints are drawn into a colour copy of the grey image: a circle of radius
@@ -509,6 +387,206 @@ static void pool_stop(mt_pool *P)
     pthread_cond_destroy(&P->cv_done);
 }
 
+/* header of a binary PGM/PPM: 0 and the geometry, or -1 */
+static int pnm_header(FILE *f, int *kind, int *w, int *h)
+{
+    if (fgetc(f) != 'P') return -1;
+    *kind = fgetc(f);
+    if (*kind != '5' && *kind != '6') return -1;
+    int maxv;
+    if (pnm_token(f, w) || pnm_token(f, h) || pnm_token(f, &maxv)) return -1;
+    return (*w < 1 || *h < 1 || maxv < 1 || maxv > 255) ? -1 : 0;
+}
+
+/* the file's pixels as 8-bit grey into dst (n bytes); colour is reduced as read_pnm_gray does */
+static int read_gray_u8(FILE *f, int kind, size_t n, unsigned char *dst, grow_buf *rgb)
+{
+    if (kind == '5') return fread(dst, 1, n, f) == n ? 0 : -1;
+    if (grow(rgb, 3 * n)) return -1;
+    const unsigned char *c = (const unsigned char *)rgb->p;
+    if (fread(rgb->p, 1, 3 * n, f) != 3 * n) return -1;
+    for (size_t i = 0; i < n; ++i)
+        dst[i] = (unsigned char)((1868 * c[3 * i + 2] + 9617 * c[3 * i + 1] + 4899 * c[3 * i] + 8192) >> 14);
+    return 0;
+}
+
+/* sift.cu:64-143: images are taken two at a time, each on its own stream and counter slot:
+ * initDeviceConstant, initDeviceVariables, upload, extractSift, getPointCount, read back, one
+ * text file per image, exactly the reference's sequence of calls per pair.  What differs is
+ * where the host work runs.  The reference decodes on the calling thread, hands each file to a
+ * detached writer thread (sift.cu:121-127) and allocates and frees every buffer per pair; its
+ * host stages take a hundred times longer than the extraction here.  So the files of the next
+ * pairs are decoded by pool threads while the GPU holds the current pair, the writers of the
+ * last pairs run beside both (a ring of PW_RING pairs of host buffers), pixels cross the link
+ * as the 8-bit values they are in the file and become floats on the device (convertTo(CV_32F),
+ * utils.cc:13, after the upload), and buffers are kept from pair to pair.  Every point is
+ * written (the reference passes count-1, sift.cu:125; sift_pipeline_drop_last_point(1)
+ * reproduces that), and the writers are waited for before the call returns. */
+#define PW_RING 4
+typedef struct {
+    grow_buf raw, rgb, h_pts, text; /* raw and h_pts are pinned */
+    const char *path, *dst_dir;
+    int device, cap;
+    int w, h, n, n_all, rc;
+} pw_img;
+
+typedef struct {
+    pw_img img[2];
+    int nq, used;
+    int load_left, save_left; /* job groups */
+} pw_pair;
+
+static void pw_load(void *arg)
+{
+    pw_img *I = (pw_img *)arg;
+    I->rc = -1;
+    sift_set_device(I->device); /* the pinned buffers belong to the caller's device */
+    FILE *f = fopen(I->path, "rb");
+    if (!f) return;
+    int kind;
+    if (pnm_header(f, &kind, &I->w, &I->h) == 0) {
+        const size_t n = (size_t)I->w * I->h;
+        if (grow(&I->raw, n) == 0 && grow(&I->h_pts, sizeof(SiftPoint) * (size_t)I->cap) == 0 &&
+            read_gray_u8(f, kind, n, (unsigned char *)I->raw.p, &I->rgb) == 0)
+            I->rc = 0;
+    }
+    fclose(f);
+}
+
+static void pw_save(void *arg)
+{
+    pw_img *I = (pw_img *)arg;
+    I->rc = save_sorted(I->dst_dir, I->path, (SiftPoint *)I->h_pts.p, I->n_all, I->n, &I->text);
+}
+
+static int host_thread_budget(void);
+
+int sift(const char *dst_dir, const char **src_paths, int n_imgs)
+{
+    if (!dst_dir || !src_paths || n_imgs < 0) return -1;
+    sift_params prm;
+    sift_get_params(&prm);
+    const int device = sift_get_device();
+    if (device < 0) return -1;
+    mt_pool pool;
+    int threads = host_thread_budget();
+    threads = threads < 2 ? 2 : (threads > 8 ? 8 : threads);
+    if (pool_start(&pool, threads, 4 * PW_RING + 8)) {
+        pool_stop(&pool);
+        return -1;
+    }
+    pw_pair *ring = (pw_pair *)calloc(PW_RING, sizeof(pw_pair));
+    /* per lane of a pair: device buffers and the stream, kept from pair to pair */
+    struct {
+        unsigned char *d_u8;
+        float *d_img;
+        size_t px;
+        SiftPoint *d_pts;
+        void *stream;
+    } D[2];
+    memset(D, 0, sizeof D);
+    int rc = ring ? 0 : -1;
+    for (int s = 0; ring && s < PW_RING; ++s)
+        for (int i = 0; i < 2; ++i) {
+            pw_img *I = &ring[s].img[i];
+            I->raw.pinned = I->h_pts.pinned = 1;
+            I->dst_dir = dst_dir;
+            I->device = device;
+            I->cap = prm.max_points;
+        }
+    const int n_pairs = (n_imgs + 1) / 2;
+    int submitted = 0; /* pairs whose decoding has been started */
+    for (int j = 0; j < n_pairs && rc == 0; ++j) {
+        /* decoding runs up to two pairs ahead; a ring slot is reused once its files are written */
+        for (; submitted < n_pairs && submitted <= j + 2; ++submitted) {
+            pw_pair *P = &ring[submitted % PW_RING];
+            pool_wait(&pool, &P->save_left);
+            for (int i = 0; i < P->nq && P->used; ++i)
+                if (P->img[i].rc) rc = -1;
+            P->nq = (n_imgs - 2 * submitted > 1) ? 2 : 1;
+            P->used = 0;
+            for (int i = 0; i < P->nq; ++i) {
+                P->img[i].path = src_paths[2 * submitted + i];
+                pool_submit(&pool, pw_load, &P->img[i], &P->load_left);
+            }
+        }
+        if (rc) break;
+        pw_pair *P = &ring[j % PW_RING];
+        pool_wait(&pool, &P->load_left);
+        for (int i = 0; i < P->nq && rc == 0; ++i) {
+            pw_img *I = &P->img[i];
+            if (I->rc) {
+                fprintf(stderr, "Could not open or find the image %s\n", I->path); /* utils.cc:15 */
+                rc = -1;
+                break;
+            }
+            const size_t need = (size_t)I->w * I->h;
+            if (D[i].px < need) {
+                if (D[i].d_u8) sift_dev_free(D[i].d_u8);
+                if (D[i].d_img) sift_dev_free(D[i].d_img);
+                D[i].d_u8 = NULL;
+                D[i].d_img = NULL;
+                D[i].px = 0;
+                rc |= sift_dev_malloc((void **)&D[i].d_u8, need);
+                if (!rc) rc |= sift_dev_malloc((void **)&D[i].d_img, need * sizeof(float));
+                if (!rc) D[i].px = need;
+            }
+            if (!rc && !D[i].d_pts) rc |= sift_dev_malloc((void **)&D[i].d_pts, sizeof(SiftPoint) * (size_t)prm.max_points);
+            if (!rc && !D[i].stream) rc |= sift_stream_create(&D[i].stream);
+        }
+        if (rc) break;
+        /* sift.cu:99-127 */
+        initDeviceConstant();
+        initDeviceVariables();
+        for (int i = 0; i < P->nq; ++i) {
+            pw_img *I = &P->img[i];
+            rc |= sift_memcpy_h2d_async(D[i].d_u8, I->raw.p, (size_t)I->w * I->h, D[i].stream);
+            rc |= sift_convert_u8_f32(D[i].d_img, I->w, D[i].d_u8, I->w, I->w, I->h, D[i].stream);
+        }
+        for (int i = 0; i < P->nq; ++i)
+            extractSift(D[i].d_pts, D[i].d_img, P->img[i].w, P->img[i].w, P->img[i].h, D[i].stream, i, 0);
+        for (int i = 0; i < P->nq && rc == 0; ++i) {
+            int n = getPointCount(i);
+            if (n < 0) {
+                rc = -1;
+                break;
+            }
+            pw_img *I = &P->img[i];
+            if (n > 0) rc |= sift_memcpy_d2h_async(I->h_pts.p, D[i].d_pts, sizeof(SiftPoint) * (size_t)n, D[i].stream);
+            I->n_all = n;
+            if (g_drop_last) n -= 1;
+            I->n = n < 0 ? 0 : n;
+        }
+        for (int i = 0; i < P->nq; ++i)
+            if (D[i].stream) rc |= sift_stream_sync(D[i].stream);
+        if (rc) break;
+        P->used = 1;
+        for (int i = 0; i < P->nq; ++i) pool_submit(&pool, pw_save, &P->img[i], &P->save_left);
+    }
+    for (int s = 0; ring && s < PW_RING; ++s) {
+        pool_wait(&pool, &ring[s].load_left);
+        pool_wait(&pool, &ring[s].save_left);
+        for (int i = 0; i < ring[s].nq && ring[s].used; ++i)
+            if (ring[s].img[i].rc) rc = -1;
+    }
+    pool_stop(&pool);
+    for (int s = 0; ring && s < PW_RING; ++s)
+        for (int i = 0; i < 2; ++i) {
+            release(&ring[s].img[i].raw);
+            release(&ring[s].img[i].rgb);
+            release(&ring[s].img[i].h_pts);
+            release(&ring[s].img[i].text);
+        }
+    for (int i = 0; i < 2; ++i) {
+        if (D[i].stream) sift_stream_destroy(D[i].stream);
+        if (D[i].d_u8) sift_dev_free(D[i].d_u8);
+        if (D[i].d_img) sift_dev_free(D[i].d_img);
+        if (D[i].d_pts) sift_dev_free(D[i].d_pts);
+    }
+    free(ring);
+    return rc ? -1 : 0;
+}
+
 #define MT_SETS 3
 #define MT_MAX_BATCH 32
 
@@ -519,7 +597,7 @@ typedef struct {
     int image;      /* index into the caller's list */
     int status;     /* 0 decoded; 1 another geometry than the set's (done later, alone); < 0 error */
     int n_points;
-    grow_buf text;
+    grow_buf text, rgb;
 } mt_item;
 
 typedef struct mt_set {
@@ -541,22 +619,12 @@ typedef struct mt_worker {
     int n_imgs;
     int *counts;
     int rc;
+    char err[512]; /* the worker thread's last library error, for the thread that started it */
     pthread_t thread;
     mt_pool pool;
     void *stream;
     mt_set set[MT_SETS];
 } mt_worker;
-
-/* header of a binary PGM/PPM: 0 and the geometry, or -1 */
-static int pnm_header(FILE *f, int *kind, int *w, int *h)
-{
-    if (fgetc(f) != 'P') return -1;
-    *kind = fgetc(f);
-    if (*kind != '5' && *kind != '6') return -1;
-    int maxv;
-    if (pnm_token(f, w) || pnm_token(f, h) || pnm_token(f, &maxv)) return -1;
-    return (*w < 1 || *h < 1 || maxv < 1 || maxv > 255) ? -1 : 0;
-}
 
 static int peek_geometry(const char *path, int *w, int *h)
 {
@@ -585,17 +653,7 @@ static void decode_job(void *arg)
         } else {
             const size_t n = (size_t)w * h;
             unsigned char *dst = (unsigned char *)S->h_img.p + n * (size_t)it->k;
-            if (kind == '5') {
-                if (fread(dst, 1, n, f) == n) it->status = 0;
-            } else {
-                unsigned char *rgb = (unsigned char *)malloc(3 * n);
-                if (rgb && fread(rgb, 1, 3 * n, f) == 3 * n) {
-                    for (size_t i = 0; i < n; ++i)
-                        dst[i] = (unsigned char)((1868 * rgb[3 * i + 2] + 9617 * rgb[3 * i + 1] + 4899 * rgb[3 * i] + 8192) >> 14);
-                    it->status = 0;
-                }
-                free(rgb);
-            }
+            if (read_gray_u8(f, kind, n, dst, &it->rgb) == 0) it->status = 0;
         }
     }
     fclose(f);
@@ -670,11 +728,15 @@ static void *worker_main(void *arg)
 {
     mt_worker *W = (mt_worker *)arg;
     W->rc = -1;
-    if (sift_set_device(W->device)) return NULL;
-    if (sift_stream_create(&W->stream)) return NULL;
+    sift_clear_error();
+    if (sift_set_device(W->device) || sift_stream_create(&W->stream)) {
+        snprintf(W->err, sizeof W->err, "%s", sift_last_error());
+        return NULL;
+    }
     if (pool_start(&W->pool, W->pool_threads, 2 * MT_SETS * MT_MAX_BATCH + 8)) {
         pool_stop(&W->pool); /* (joins whatever threads did start) */
         sift_stream_destroy(W->stream);
+        snprintf(W->err, sizeof W->err, "worker %d: could not start its host threads", W->index);
         return NULL;
     }
     /* this worker's images, in list order */
@@ -702,6 +764,9 @@ static void *worker_main(void *arg)
                 int w = 0, h = 0;
                 if (peek_geometry(W->paths[list[first]], &w, &h)) {
                     fprintf(stderr, "Could not open or find the image %s\n", W->paths[list[first]]); /* utils.cc:15 */
+                    char msg[400];
+                    snprintf(msg, sizeof msg, "Could not open or find the image %.300s", W->paths[list[first]]);
+                    sift_set_last_error(msg);
                     rc = -1;
                     break;
                 }
@@ -725,6 +790,9 @@ static void *worker_main(void *arg)
                 for (int k = 0; k < S->n; ++k) {
                     if (S->item[k].status < 0) {
                         fprintf(stderr, "Could not open or find the image %s\n", W->paths[S->item[k].image]);
+                        char msg[400];
+                        snprintf(msg, sizeof msg, "Could not open or find the image %.300s", W->paths[S->item[k].image]);
+                        sift_set_last_error(msg);
                         rc = -1;
                     } else if (S->item[k].status == 1) {
                         if (pass == 0) later[n_later++] = S->item[k].image;
@@ -753,11 +821,15 @@ static void *worker_main(void *arg)
         if (S->d_img) sift_dev_free(S->d_img);
         if (S->d_pts) sift_dev_free(S->d_pts);
         if (S->d_counts) sift_dev_free(S->d_counts);
-        for (int k = 0; k < MT_MAX_BATCH; ++k) release(&S->item[k].text);
+        for (int k = 0; k < MT_MAX_BATCH; ++k) {
+            release(&S->item[k].text);
+            release(&S->item[k].rgb);
+        }
     }
     sift_stream_destroy(W->stream);
     free(mine);
     free(later);
+    if (rc) snprintf(W->err, sizeof W->err, "%s", sift_last_error());
     W->rc = rc;
     return NULL;
 }
@@ -812,10 +884,16 @@ int sift_extract_list_multi(const char *dst_dir, const char **src_paths, int n_i
         }
         ++started;
     }
+    const char *first_err = NULL;
     for (int g = 0; g < started; ++g) {
         pthread_join(W[g].thread, NULL);
-        if (W[g].rc) rc = -1;
+        if (W[g].rc) {
+            rc = -1;
+            if (!first_err && W[g].err[0]) first_err = W[g].err;
+        }
     }
+    /* the workers' errors live in their own threads: the first one becomes the caller's */
+    if (rc) sift_set_last_error(first_err ? first_err : "sift_extract_list_multi: a worker failed (see stderr)");
     free(W);
     return rc;
 }

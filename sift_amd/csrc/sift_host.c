@@ -77,6 +77,16 @@ static int g_host_count_n[MAX_DEV];
 static int g_lanes = N_LANES;
 static int g_next_lane[MAX_DEV]; /* the lane the next non-blocking batch call starts on */
 static unsigned *g_slot_counter[MAX_DEV]; /* device, SIFT_MAX_SLOTS words */
+/* Pinned host mirror of the slot counters: the last kernel of every extractSift writes the
+ * slot's count there, so getPointCount is one event wait and a load, not a copy and a sync. */
+static unsigned *g_slot_host[MAX_DEV];
+/* initDeviceVariables has been called and the slot has not extracted since: its count is zero,
+ * and the next extractSift zeroes the device word in its own first kernel, on its own stream. */
+static int g_slot_reset[MAX_DEV][SIFT_MAX_SLOTS];
+/* the most recent batch call on each device: where its images sit in the lane arenas */
+static struct {
+    int valid, n, chunk, n_sets, lane0, lanes;
+} g_last_batch[MAX_DEV];
 static int g_chunk = 256;
 static int g_queue_cap = QUEUE_CAP; /* 0: no pre-filter, dense detector only */
 static __thread char g_err[512] = ""; /* the calling thread's last error */
@@ -90,6 +100,12 @@ static void set_err(const char *fmt, ...)
 }
 
 const char *sift_last_error(void) { return g_err; }
+/* makes msg the calling thread's last error (a worker thread's message, handed to the thread
+ * that started it) */
+void sift_set_last_error(const char *msg)
+{
+    snprintf(g_err, sizeof g_err, "%s", msg ? msg : "");
+}
 void sift_clear_error(void) { g_err[0] = 0; }
 
 static int fail_hl(int code, const char *what)
@@ -324,6 +340,12 @@ void sift_shutdown(void)
             hl_free(g_slot_counter[dev]);
             g_slot_counter[dev] = NULL;
         }
+        if (g_slot_host[dev]) {
+            hl_host_free(g_slot_host[dev]);
+            g_slot_host[dev] = NULL;
+        }
+        memset(g_slot_reset[dev], 0, sizeof g_slot_reset[dev]);
+        g_last_batch[dev].valid = 0;
         unlock_device(dev);
     }
 }
@@ -337,7 +359,18 @@ static int ensure_slot_counter(int dev)
     if (r) return fail_hl(r, "allocating slot counters");
     r = hl_memset_async(p, 0, sizeof(unsigned) * SIFT_MAX_SLOTS, NULL);
     if (!r) r = hl_stream_sync(NULL);
-    if (r) return fail_hl(r, "zeroing slot counters");
+    if (r) {
+        hl_free(p);
+        return fail_hl(r, "zeroing slot counters");
+    }
+    void *hp = NULL;
+    r = hl_host_alloc(&hp, sizeof(unsigned) * SIFT_MAX_SLOTS);
+    if (r) {
+        hl_free(p);
+        return fail_hl(r, "allocating the host copy of the slot counters");
+    }
+    memset(hp, 0, sizeof(unsigned) * SIFT_MAX_SLOTS);
+    g_slot_host[dev] = (unsigned *)hp;
     g_slot_counter[dev] = (unsigned *)p;
     return 0;
 }
@@ -409,26 +442,30 @@ static int ensure_arena(slot_ctx *c, int w, int h, int oct0, int nimg)
 
     size_t bytes[5];
     plan_arena(c, w, h, oct0, nimg, g_queue_cap, bytes);
-    void *p = NULL;
-    int r = hl_malloc(&p, bytes[0]);
-    if (r) return fail_hl(r, "allocating arena");
-    c->arena = (float *)p;
-    r = hl_malloc(&p, bytes[1]);
-    if (r) return fail_hl(r, "allocating group counters");
-    c->counts = (unsigned *)p;
-    r = hl_malloc(&p, bytes[2]);
-    if (r) return fail_hl(r, "allocating candidate queue");
-    c->queue = (unsigned *)p;
-    r = hl_malloc(&p, bytes[3]);
-    if (r) return fail_hl(r, "allocating candidate lists");
-    c->cand = (unsigned *)p;
-    if (bytes[4]) {
-        r = hl_malloc(&p, bytes[4]);
-        if (r) return fail_hl(r, "allocating refined-point records");
-        c->sub = p;
+    static const char *const what[5] = {"allocating arena", "allocating group counters", "allocating candidate queue",
+                                        "allocating candidate lists", "allocating refined-point records"};
+    void *region[5] = {NULL, NULL, NULL, NULL, NULL};
+    int r = 0;
+    for (int k = 0; k < 5 && !r; ++k) {
+        if (!bytes[k]) continue; /* (the refined-point records exist in profile "lowe" only) */
+        r = hl_malloc(&region[k], bytes[k]);
+        if (r) fail_hl(r, what[k]);
     }
-    r = hl_event_create(&c->done);
-    if (r) return fail_hl(r, "creating slot event");
+    if (!r) {
+        r = hl_event_create(&c->done);
+        if (r) fail_hl(r, "creating slot event");
+    }
+    if (r) { /* nothing half-built stays behind: the slot is empty again */
+        for (int k = 0; k < 5; ++k)
+            if (region[k]) hl_free(region[k]);
+        memset(c, 0, sizeof *c);
+        return -1;
+    }
+    c->arena = (float *)region[0];
+    c->counts = (unsigned *)region[1];
+    c->queue = (unsigned *)region[2];
+    c->cand = (unsigned *)region[3];
+    c->sub = region[4];
     c->valid = 1;
     return 0;
 }
@@ -573,11 +610,16 @@ void initDeviceVariables(void)
         if (r) fail_hl(r, "initDeviceVariables: static scratch buffer");
     }
     if (ensure_slot_counter(dev) == 0) {
-        /* the reference's cudaMemcpyToSymbol is ordered after all earlier work */
-        int r = hl_device_sync();
-        if (!r) r = hl_memset_async(g_slot_counter[dev], 0, sizeof(unsigned) * SIFT_MAX_SLOTS, NULL);
-        if (!r) r = hl_stream_sync(NULL);
-        if (r) fail_hl(r, "initDeviceVariables");
+        /* The reference zeroes its two counters with a blocking copy that follows all earlier
+         * work (cudaSiftH.cu:120-127).  Here the slots' own work is waited for through their
+         * events (normally long finished: getPointCount has been called), the host copies of the
+         * counts are zeroed now, and each device word is zeroed by the first kernel of the slot's
+         * next extractSift, on that call's stream: no device-wide wait, no copy. */
+        for (int sl = 0; sl < SIFT_MAX_SLOTS; ++sl) {
+            drain_slot(&g_slots[dev][sl], "initDeviceVariables");
+            g_slot_host[dev][sl] = 0u;
+            g_slot_reset[dev][sl] = 1;
+        }
     }
     unlock_device(dev);
 }
@@ -613,8 +655,20 @@ void extractSift(SiftPoint *siftPt, float *d_src, int width, int pitch, int heig
         slot_ctx *c = &g_slots[dev][streamIdx];
         if (ensure_arena(c, width, height, octaveIdx, 1))
             break;
-        enqueue_extract(c, siftPt, NULL, d_src, 0, 0, 1, pitch, octaveIdx,
-                        g_slot_counter[dev] + streamIdx, 0, NULL, stream);
+        /* The slot's planes, queues and counters may still be in use by its previous call,
+         * which may have been given another stream (the reference's extractSift blocks, so
+         * there any two calls on one streamIdx are ordered, cudaSiftH.cu:22-24,158-177). */
+        if (c->busy) {
+            int r = hl_stream_wait_event(stream, c->done);
+            if (r) {
+                fail_hl(r, "extractSift: ordering behind the slot's previous call");
+                break;
+            }
+        }
+        const int reset = g_slot_reset[dev][streamIdx];
+        if (enqueue_extract(c, siftPt, NULL, d_src, 0, 0, 1, pitch, octaveIdx, g_slot_counter[dev] + streamIdx,
+                            reset, g_slot_host[dev] + streamIdx, stream) == 0)
+            g_slot_reset[dev][streamIdx] = 0;
     } while (0);
     unlock_device(dev);
 }
@@ -634,15 +688,9 @@ int getPointCount(int streamIdx)
         slot_ctx *c = &g_slots[dev][streamIdx];
         if (drain_slot(c, "getPointCount"))
             break;
-        int r = 0;
-        unsigned v = 0;
-        r = hl_memcpy_async(&v, g_slot_counter[dev] + streamIdx, sizeof v, 2, NULL);
-        if (!r) r = hl_stream_sync(NULL);
-        if (r) {
-            fail_hl(r, "getPointCount");
-            break;
-        }
-        result = (int)v;
+        /* the slot's last kernel wrote the count to pinned host memory (cudaSiftH.cu:323-328
+         * copies it from the device symbol with a blocking call) */
+        result = (int)*(volatile unsigned *)(g_slot_host[dev] + streamIdx);
     } while (0);
     unlock_device(dev);
     return result;
@@ -824,14 +872,22 @@ static void batch_sets(int n, int *chunk, int *n_sets)
 int sift_debug_batch_slot(int n, int i, int *slot, int *image)
 {
     if (n < 1 || i < 0 || i >= n || !slot || !image) return -1;
-    int chunk, n_sets;
-    batch_sets(n, &chunk, &n_sets);
-    const int lanes = n_sets < g_lanes ? n_sets : g_lanes;
-    const int k = i / chunk;
-    if (k + lanes < n_sets) return -1; /* a later set has reused that lane's arena */
-    *slot = BATCH_SLOT + k % lanes;
-    *image = i % chunk;
-    return 0;
+    const int dev = hl_get_device();
+    if (dev < 0 || dev >= MAX_DEV) return -1;
+    int rc = -1;
+    pthread_mutex_lock(&g_dev_mu[dev]);
+    /* the lanes the most recent batch call (blocking or not) really used */
+    if (g_last_batch[dev].valid && g_last_batch[dev].n == n) {
+        const int chunk = g_last_batch[dev].chunk, n_sets = g_last_batch[dev].n_sets;
+        const int lanes = g_last_batch[dev].lanes, k = i / chunk;
+        if (k + lanes >= n_sets) { /* (a later set has not reused that lane's arena) */
+            *slot = BATCH_SLOT + (g_last_batch[dev].lane0 + k) % g_lanes;
+            *image = i % chunk;
+            rc = 0;
+        }
+    }
+    pthread_mutex_unlock(&g_dev_mu[dev]);
+    return rc;
 }
 
 void sift_set_strip_rows(int rows) { hl_set_pyramid_strip_rows(rows > 0 ? rows : 0); }
@@ -867,6 +923,7 @@ static int extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
          * arena, and calls that share a lane follow each other on its stream. */
         const int lane0 = h_counts ? 0 : g_next_lane[dev] % g_lanes;
         if (!h_counts) g_next_lane[dev] = (lane0 + n_sets) % g_lanes;
+        g_last_batch[dev].valid = 0;
         if (ensure_lanes(dev))
             break;
         int bad = 0;
@@ -944,6 +1001,12 @@ static int extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
             fail_hl(r, "finishing batch");
             break;
         }
+        g_last_batch[dev].n = n;
+        g_last_batch[dev].chunk = chunk;
+        g_last_batch[dev].n_sets = n_sets;
+        g_last_batch[dev].lane0 = lane0;
+        g_last_batch[dev].lanes = lanes;
+        g_last_batch[dev].valid = 1;
         rc = 0;
     } while (0);
     unlock_device(dev);
@@ -1104,6 +1167,7 @@ void copyDeviceData(float *dst, float *src, int width, int pitch, int height, vo
 
 int sift_device_count(void) { return hl_device_count(); }
 int sift_set_device(int dev) { WRAP(hl_set_device(dev), "sift_set_device"); }
+int sift_get_device(void) { return hl_get_device(); }
 int sift_dev_malloc(void **p, size_t bytes) { WRAP(hl_malloc(p, bytes), "sift_dev_malloc"); }
 int sift_dev_malloc_pitch(float **p, int *pitch_floats, int width, int height)
 {
@@ -1135,6 +1199,10 @@ int sift_memcpy_h2d_async(void *d, const void *h, size_t n, void *s)
 int sift_memcpy_d2h_async(void *h, const void *d, size_t n, void *s)
 {
     WRAP(hl_memcpy_async(h, d, n, 2, s), "sift_memcpy_d2h_async");
+}
+int sift_convert_u8_f32(float *d, int dp, const unsigned char *src, int sp, int w, int h, void *s)
+{
+    WRAP(hl_u8_to_f32(d, dp, src, sp, w, h, s), "sift_convert_u8_f32");
 }
 int sift_stream_create(void **s) { WRAP(hl_stream_create(s), "sift_stream_create"); }
 int sift_stream_destroy(void *s) { WRAP(hl_stream_destroy(s), "sift_stream_destroy"); }

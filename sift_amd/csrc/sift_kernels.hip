@@ -390,18 +390,23 @@ __global__ __launch_bounds__(64, (S == 2 ? PYR_WAVES_S2 : PYR_WAVES_S3)) void py
     // The fetches are inline assembly so that the compiler neither tracks them (it would
     // wait for the youngest of them in front of every LDS read) nor counts them; extra
     // operations the compiler adds only make the waits below more conservative.
+    // (m0 is named as clobbered so that the compiler keeps no value of its own in it across the
+    // statements; it answers with a warning about reserved registers, which is switched off here)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
     auto fetch = [&](const int slot) __attribute__((always_inline)) {
         const int yi = yi_next++;
         const unsigned row = (yi >= 0 && yi < h) ? (unsigned)(SX * yi) * (unsigned)src_pitch * (unsigned)ES : FZ_DROP;
         const unsigned dst = lds_base + (unsigned)slot * 512u;
         if (SRC_MODE == 1) { // a byte arrives as the integer of its value
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_ubyte %1, %2, %3 offen lds" ::"s"(dst), "v"(col_off[0]), "s"(src_rs), "s"(row) : "memory");
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_ubyte %1, %2, %3 offen lds" ::"s"(dst + 256u), "v"(col_off[1]), "s"(src_rs), "s"(row) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_ubyte %1, %2, %3 offen lds" ::"s"(dst), "v"(col_off[0]), "s"(src_rs), "s"(row) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_ubyte %1, %2, %3 offen lds" ::"s"(dst + 256u), "v"(col_off[1]), "s"(src_rs), "s"(row) : "memory", "m0");
         } else {
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(dst), "v"(col_off[0]), "s"(src_rs), "s"(row) : "memory");
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(dst + 256u), "v"(col_off[1]), "s"(src_rs), "s"(row) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(dst), "v"(col_off[0]), "s"(src_rs), "s"(row) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(dst + 256u), "v"(col_off[1]), "s"(src_rs), "s"(row) : "memory", "m0");
         }
     };
+#pragma clang diagnostic pop
     // vector-memory operations issued between a row's fetch and its first read: the NP
     // stores of the step that fetched it, FZ_PF - 1 whole steps, and this step's fetch
     constexpr int FZ_WAIT = NP + (NP + 2) * (FZ_PF - 1) + 2;
@@ -2192,6 +2197,20 @@ __global__ __launch_bounds__(256) void gradient_kernel(float *dst, const float *
     dst[g + (long)p * h] = d;
 }
 
+// 8-bit grey pixels to floats, four per lane where the row allows
+__global__ __launch_bounds__(256) void u8_to_f32_kernel(float *__restrict__ dst, int dp, const unsigned char *__restrict__ src,
+                                                        int sp, int w, int h)
+{
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const unsigned char *s = src + (long)sp * y + x;
+    float *d = dst + (long)dp * y + x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (x + k < w) d[k] = (float)s[k];
+}
+
 // ---- static scratch -------------------------------------------------------------
 // Scratch of the entry point that allocates nothing (sift_extract_noalloc): blur planes,
 // counters, candidate queues and lists of ONE image.  Every GPU the library runs on holds
@@ -2724,6 +2743,13 @@ int hl_zero_words(unsigned *a, long na, unsigned *b, long nb, void *stream)
     const long blocks = (na + nb + 1023) / 1024; // four words per thread
     hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0,
                        (hipStream_t)stream, a, na, b, nb);
+    return launch_status();
+}
+
+int hl_u8_to_f32(float *dst, int dp, const unsigned char *src, int sp, int w, int h, void *stream)
+{
+    if (!dst || !src || w < 1 || h < 1 || dp < w || sp < w) return -1001;
+    hipLaunchKernelGGL(u8_to_f32_kernel, dim3(idivup(w, 1024), h), dim3(256), 0, (hipStream_t)stream, dst, dp, src, sp, w, h);
     return launch_status();
 }
 

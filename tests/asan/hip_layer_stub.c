@@ -18,8 +18,14 @@ int hl_set_device(int dev)
     return 0;
 }
 int hl_get_device(void) { return g_dev; }
+/* test hook: the n-th device allocation from now on fails (0 = the next one; -1 = none) */
+int hl_stub_malloc_fail_at = -1;
 int hl_malloc(void **p, size_t bytes)
 {
+    if (hl_stub_malloc_fail_at >= 0 && hl_stub_malloc_fail_at-- == 0) {
+        *p = NULL;
+        return -2;
+    }
     *p = malloc(bytes ? bytes : 1);
     return *p ? 0 : -2;
 }
@@ -75,7 +81,11 @@ int hl_stream_wait_event(void *stream, void *e)
     (void)stream;
     return e ? 0 : -1;
 }
-int hl_host_alloc(void **p, size_t bytes) { return hl_malloc(p, bytes); }
+int hl_host_alloc(void **p, size_t bytes)
+{
+    *p = malloc(bytes ? bytes : 1);
+    return *p ? 0 : -2;
+}
 int hl_host_free(void *p) { return hl_free(p); }
 const char *hl_error_string(int code)
 {
@@ -239,4 +249,12 @@ int hl_copy(float *dst, const float *src, int w, int p, int h, void *stream)
 {
     (void)stream;
     return (dst && src && w > 0 && p >= w && h > 0) ? 0 : -1001;
+}
+int hl_u8_to_f32(float *dst, int dp, const unsigned char *src, int sp, int w, int h, void *stream)
+{
+    (void)stream;
+    if (!dst || !src || w < 1 || h < 1 || dp < w || sp < w) return -1001;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) dst[(long)dp * y + x] = (float)src[(long)sp * y + x];
+    return 0;
 }

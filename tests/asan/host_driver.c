@@ -28,10 +28,13 @@ static void write_pnm(const char *path, int kind, int w, int h, unsigned seed, l
     fclose(f);
 }
 
+extern int hl_stub_malloc_fail_at; /* hip_layer_stub.c */
+
 static void *device_thread(void *arg)
 {
     const int dev = (int)(intptr_t)arg;
     CHECK(sift_set_device(dev) == 0);
+    CHECK(sift_get_device() == dev);
     float *img;
     SiftPoint *pts;
     CHECK(sift_dev_malloc((void **)&img, sizeof(float) * 300 * 200) == 0);
@@ -41,6 +44,20 @@ static void *device_thread(void *arg)
         extractSift(pts, img, 300 - rep, 300, 200 - rep, NULL, rep % SIFT_MAX_SLOTS, 0);
         CHECK(sift_last_error()[0] == 0);
         CHECK(getPointCount(rep % SIFT_MAX_SLOTS) == 0);
+    }
+    {   /* the entry that allocates nothing, on this device's copy of the static buffer, and a batch
+         * through this device's lane arenas */
+        unsigned *cnt;
+        int hc[3];
+        CHECK(sift_dev_malloc((void **)&cnt, sizeof(unsigned)) == 0);
+        CHECK(sift_extract_noalloc(pts, cnt, img, 300, 300, 200, NULL) == 0);
+        CHECK(sift_extract_noalloc(pts, cnt, img, 150, 300, 100, NULL) == 0);
+        SiftPoint *bp;
+        CHECK(sift_dev_malloc((void **)&bp, sizeof(SiftPoint) * 2500 * 3) == 0);
+        CHECK(sift_extract_batch(bp, NULL, hc, img, 100L * 200, 3, 100, 100, 200, NULL) == 0);
+        CHECK(hc[0] == 0 && hc[2] == 0);
+        sift_dev_free(bp);
+        sift_dev_free(cnt);
     }
     sift_shutdown();
     sift_dev_free(img);
@@ -95,7 +112,30 @@ int main(int argc, char **argv)
     CHECK(sift_stream_create(&stream) == 0);
     extractSift(d_pts, d_img, 801, pitch, 603, stream, 0, 0);
     CHECK(sift_last_error()[0] == 0 && getPointCount(0) == 0);
+    {   /* two calls in a row on one slot from two streams, no getPointCount in between: the second
+         * is ordered behind the first through the slot's event */
+        void *stream2;
+        CHECK(sift_stream_create(&stream2) == 0);
+        extractSift(d_pts, d_img, 801, pitch, 603, stream, 0, 0);
+        extractSift(d_pts, d_img, 801, pitch, 603, stream2, 0, 0);
+        CHECK(sift_last_error()[0] == 0 && getPointCount(0) == 0);
+        initDeviceVariables();
+        CHECK(getPointCount(0) == 0 && getPointCount(1) == 0);
+        CHECK(sift_stream_destroy(stream2) == 0);
+    }
     CHECK(sift_stream_destroy(stream) == 0);
+    {   /* an allocation that fails half-way through a slot's arena leaves the slot empty (nothing
+         * leaks, and the next call plans it afresh) */
+        for (int k = 0; k < 5; ++k) {
+            hl_stub_malloc_fail_at = k;
+            extractSift(d_pts, d_img, 640 + k, pitch, 400, NULL, 3, 0);
+            CHECK(sift_last_error()[0] != 0);
+            sift_clear_error();
+            hl_stub_malloc_fail_at = -1;
+        }
+        extractSift(d_pts, d_img, 640, pitch, 400, NULL, 3, 0);
+        CHECK(sift_last_error()[0] == 0 && getPointCount(3) == 0);
+    }
     extractSift(d_pts, d_img, 400, pitch, 300, NULL, 0, 1); /* other geometry, same slot, start octave 1 */
     CHECK(sift_last_error()[0] == 0 && getPointCount(0) == 0);
     extractSift(d_pts, d_img, 900, pitch, 300, NULL, 0, 0); /* pitch < width */
@@ -136,6 +176,11 @@ int main(int argc, char **argv)
     sift_set_batch_lanes(2);
     sift_set_batch_chunk(256);
     CHECK(sift_extract_batch_async(d_bpts, NULL, d_counts, d_batch, 0, (long)w * h, n, w, w, h, NULL) == 0);
+    CHECK(sift_debug_batch_slot(n, 5, &slot, &image) == 0 && slot == SIFT_MAX_SLOTS && image == 5);
+    /* the next non-blocking call starts on the other lane, and the slot reported follows it */
+    CHECK(sift_extract_batch_async(d_bpts, NULL, d_counts, d_batch, 0, (long)w * h, n, w, w, h, NULL) == 0);
+    CHECK(sift_debug_batch_slot(n, 5, &slot, &image) == 0 && slot == SIFT_MAX_SLOTS + 1 && image == 5);
+    CHECK(sift_debug_batch_slot(n - 1, 5, &slot, &image) != 0); /* not the most recent batch's size */
     CHECK(sift_extract_batch_async(d_bpts, NULL, NULL, d_batch, 0, (long)w * h, n, w, w, h, NULL) != 0);
     CHECK(sift_extract_batch(d_bpts, NULL, counts, d_batch, 10, n, w, w, h, NULL) != 0); /* stride too small */
     sift_clear_error();
@@ -258,15 +303,22 @@ int main(int argc, char **argv)
     CHECK(sift(tmp, list, 3) == 0);
     sift_pipeline_drop_last_point(0);
     int lc[5];
-    for (int workers = 1; workers <= 3; ++workers) {
+    for (int workers = 1; workers <= 4; ++workers) { /* 2 and 4 workers: both pretend devices, one and two workers each */
         CHECK(sift_extract_list_multi(tmp, list, 5, workers, lc) == 0);
         for (int i = 0; i < 5; ++i) CHECK(lc[i] == 0);
     }
     CHECK(sift_extract_list_multi(NULL, list, 5, 2, NULL) == 0);
     const char *bad_list[3] = {path[0], path[6], path[2]};
+    sift_clear_error();
     CHECK(sift_extract_list_multi(tmp, bad_list, 3, 1, lc) != 0);
+    CHECK(strstr(sift_last_error(), "missing.pgm") != NULL); /* the worker's message reaches this thread */
     const char *bad_list2[2] = {path[4], path[0]};
+    sift_clear_error();
     CHECK(sift_extract_list_multi(tmp, bad_list2, 2, 2, lc) != 0);
+    CHECK(sift_last_error()[0] != 0);
+    sift_clear_error();
+    CHECK(sift(tmp, bad_list, 3) != 0);
+    CHECK(sift(tmp, bad_list2, 2) != 0);
     CHECK(sift_extract_list_multi(tmp, list, 0, 1, NULL) == 0);
     CHECK(sift_list_partition(13, 4) == 1);
 

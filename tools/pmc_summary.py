@@ -57,10 +57,14 @@ def main(root):
     if len(sys.argv) > 3 and "pyramid" in acc and "FETCH_SIZE" in acc["pyramid"] and "WRITE_SIZE" in acc["pyramid"]:
         import json
 
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        from bench import source_hash  # the counted bytes belong to these kernel sources
+
         c = {n: v[0] / max(v[1], 1) for n, v in acc["pyramid"].items()}
         rd, wr = c["FETCH_SIZE"] * 1024 * 2, c["WRITE_SIZE"] * 1024
         json.dump({"pyramid_kernel": {"batch": int(sys.argv[3]), "hbm_bytes_per_launch": rd + wr,
                                       "read_bytes": rd, "write_bytes": wr,
+                                      "source_hash": source_hash(),
                                       "source": "rocprofv3 --pmc FETCH_SIZE (x2, calibrated on dword-per-lane reads of a "
                                                 "known size) and WRITE_SIZE, separate passes, mean over launches"}},
                   open(sys.argv[2], "w"), indent=1)

@@ -28,10 +28,10 @@ __global__ __launch_bounds__(64) void k(const float *src, const unsigned char *s
         const unsigned dstaddr = base + r * 512 + (r == 7 ? 256 : 0);
         if (r == 5 || r == 6)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_ubyte %1, %2, %3 offen lds"
-                         :: "s"(dstaddr), "v"(voff[r]), "s"(rb), "s"(soff[r]) : "memory");
+                         :: "s"(dstaddr), "v"(voff[r]), "s"(rb), "s"(soff[r]) : "memory", "m0");
         else
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
-                         :: "s"(dstaddr), "v"(voff[r]), "s"(rs), "s"(soff[r]) : "memory");
+                         :: "s"(dstaddr), "v"(voff[r]), "s"(rs), "s"(soff[r]) : "memory", "m0");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int r = 0; r < 8; ++r) {

@@ -33,20 +33,25 @@ template <> __device__ __forceinline__ void fma_all<4>(float4 &v, float a, float
     v.w = __builtin_fmaf(v.w, a, b);
 }
 
-template <int NPL, int VW, int WAVES, int LAYOUT, int FMAS, int PF, int LDSB, int REMAP>
+//   SYNC   1: the waves of a workgroup meet at a barrier after every row (they stay in lockstep, so a
+//          workgroup's stores of one row form one contiguous 256*WAVES-byte run in time as well as in space)
+//   PERSIST 1: the grid is the resident wave count; each workgroup walks the tile list with stride gridDim
+template <int NPL, int VW, int WAVES, int LAYOUT, int FMAS, int PF, int LDSB, int REMAP, int SYNC = 0, int PERSIST = 0>
 __global__ __launch_bounds__(64 * WAVES) void strips(float *__restrict__ out, const float *__restrict__ in, int w, int p,
-                                                     int h, int rows, long out_stride, float a, float b)
+                                                     int h, int rows, long out_stride, float a, float b, int vgx = 0,
+                                                     int vgy = 0, int vgz = 0)
 {
     typedef typename Vec<VW>::T V;
     __shared__ float occ[LDSB / 4 + 1]; // caps the waves per CU
     if (a == 12345.f) occ[threadIdx.x] = b;
     if (a == 54321.f) out[0] = occ[threadIdx.x + 1];
     // XCD-aware remap: each XCD gets a contiguous run of tiles
+    const unsigned gx = PERSIST ? vgx : gridDim.x, gy = PERSIST ? vgy : gridDim.y;
+    const unsigned nwg = gx * gy * (PERSIST ? vgz : gridDim.z);
+    for (unsigned orig = PERSIST ? blockIdx.x : blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z); orig < nwg;
+         orig += PERSIST ? gridDim.x : nwg) {
     int tx, ty, tz;
     {
-        const unsigned gx = gridDim.x, gy = gridDim.y;
-        const unsigned nwg = gx * gy * gridDim.z;
-        const unsigned orig = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
         const unsigned q = nwg / 8, r = nwg % 8, xcd = orig % 8;
         const unsigned t = REMAP ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8 : orig;
         tx = (int)(t % gx);
@@ -54,7 +59,7 @@ __global__ __launch_bounds__(64 * WAVES) void strips(float *__restrict__ out, co
         tz = (int)(t / (gx * gy));
     }
     const int x = (tx * 64 * WAVES + threadIdx.x) * VW;
-    if (x >= w) return;
+    if (x >= w) { if (SYNC || PERSIST) continue; else return; }
     const int y0 = ty * rows, y1 = min(y0 + rows, h);
     const float *s = in + tz * (long)p * h + x;
     float *o = out + tz * out_stride;
@@ -109,7 +114,9 @@ __global__ __launch_bounds__(64 * WAVES) void strips(float *__restrict__ out, co
                     }
                 }
             }
+            if (SYNC) __syncthreads();
         }
+    }
     }
 }
 
@@ -175,6 +182,24 @@ __global__ __launch_bounds__(256) void flat_store(float4 *out, long n)
     for (; i < n; i += stride) out[i] = float4{1.f, 2.f, 3.f, (float)i};
 }
 
+__global__ __launch_bounds__(256) void flat_store1(float *out, long n)
+{
+    long i = blockIdx.x * 256L + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (; i < n; i += stride) out[i] = (float)i;
+}
+__global__ __launch_bounds__(256) void flat_read(const float4 *in, long n, float *sink)
+{
+    long i = blockIdx.x * 256L + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    float acc = 0.f;
+    for (; i < n; i += stride) {
+        const float4 v = in[i];
+        acc += v.x + v.y + v.z + v.w;
+    }
+    if (acc == 123.456f) *sink = acc;
+}
+
 static hipEvent_t e0, e1;
 template <class F> static float best_ms(F f)
 {
@@ -195,17 +220,19 @@ constexpr int NPL = 5;
 static const int W = 1920, H = 1080, P = 1920, NIMG = 128;
 static float *g_out, *g_in;
 
-template <int VW, int WAVES, int LAYOUT, int FMAS, int PF, int LDSB = 0, int REMAP = 1> static void run(int rows)
+template <int VW, int WAVES, int LAYOUT, int FMAS, int PF, int LDSB = 0, int REMAP = 1, int SYNC = 0, int PERSIST = 0>
+static void run(int rows, int resident_blocks = 0)
 {
     const long plane = (long)P * H;
-    dim3 grid((W + 64 * WAVES * VW - 1) / (64 * WAVES * VW), (H + rows - 1) / rows, NIMG);
+    const dim3 vgrid((W + 64 * WAVES * VW - 1) / (64 * WAVES * VW), (H + rows - 1) / rows, NIMG);
+    const dim3 grid = PERSIST ? dim3(resident_blocks) : vgrid;
     const float ms = best_ms([&] {
-        hipLaunchKernelGGL((strips<NPL, VW, WAVES, LAYOUT, FMAS, PF, LDSB, REMAP>), grid, dim3(64 * WAVES), 0, 0, g_out, g_in, W, P, H,
-                           rows, plane * NPL, 0.999f, 0.001f);
+        hipLaunchKernelGGL((strips<NPL, VW, WAVES, LAYOUT, FMAS, PF, LDSB, REMAP, SYNC, PERSIST>), grid, dim3(64 * WAVES), 0, 0, g_out,
+                           g_in, W, P, H, rows, plane * NPL, 0.999f, 0.001f, (int)vgrid.x, (int)vgrid.y, (int)vgrid.z);
     });
     const double bytes = (double)plane * NIMG * 4 * (NPL + 1);
-    printf("VW=%d waves/WG=%d layout=%s FMA/elem/plane=%3d PF=%d rows=%4d lds=%5d remap=%d: %7.3f ms  %5.2f TB/s  (%.1f us/image)\n", VW, WAVES,
-           LAYOUT == 0 ? "planar" : (LAYOUT == 1 ? "pixel " : (LAYOUT == 2 ? "rowint" : (LAYOUT == 3 ? "tiled " : "tilint"))), FMAS, PF, rows, LDSB, REMAP, ms, bytes / ms / 1e9, ms * 1e3 / NIMG);
+    printf("VW=%d waves/WG=%d layout=%s FMA/elem/plane=%3d PF=%d rows=%4d lds=%5d remap=%d sync=%d persist=%d(%d): %7.3f ms  %5.2f TB/s  (%.1f us/image)\n", VW, WAVES,
+           LAYOUT == 0 ? "planar" : (LAYOUT == 1 ? "pixel " : (LAYOUT == 2 ? "rowint" : (LAYOUT == 3 ? "tiled " : "tilint"))), FMAS, PF, rows, LDSB, REMAP, SYNC, PERSIST, resident_blocks, ms, bytes / ms / 1e9, ms * 1e3 / NIMG);
     fflush(stdout);
 }
 
@@ -222,32 +249,59 @@ template <int PF, int LDSB> static void run_rows4(int rows)
     fflush(stdout);
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    const int set = argc > 1 ? atoi(argv[1]) : 0;
     const long plane = (long)P * H;
     hipMalloc(&g_out, plane * NPL * NIMG * 4);
     hipMalloc(&g_in, plane * NIMG * 4);
     hipMemset(g_in, 0, plane * NIMG * 4);
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    {
-        const long n = plane * NIMG / 4;
-        float ms = best_ms([&] { hipLaunchKernelGGL(flat_copy, dim3(256 * 16), dim3(256), 0, 0, (float4 *)g_out, (const float4 *)g_in, n); });
-        printf("flat float4 copy: %.3f ms  %.2f TB/s (read + write)\n", ms, 2.0 * n * 16 / ms / 1e9);
-        const long m = plane * NPL * NIMG / 4;
-        ms = best_ms([&] { hipLaunchKernelGGL(flat_store, dim3(256 * 16), dim3(256), 0, 0, (float4 *)g_out, m); });
-        printf("flat float4 store: %.3f ms  %.2f TB/s\n", ms, (double)m * 16 / ms / 1e9);
+    if (set == 0 || set == 1) { // flat copies, stores and reads over grid sizes (256-thread blocks)
+        const long n = plane * NIMG / 4, m = plane * NPL * NIMG / 4;
+        for (int blocks : {256, 512, 768, 1024, 1280, 1536, 2048, 4096, 16384}) {
+            float ms = best_ms([&] { hipLaunchKernelGGL(flat_copy, dim3(blocks), dim3(256), 0, 0, (float4 *)g_out, (const float4 *)g_in, n); });
+            printf("%5d blocks: flat float4 copy %.3f ms %.2f TB/s (read + write)", blocks, ms, 2.0 * n * 16 / ms / 1e9);
+            ms = best_ms([&] { hipLaunchKernelGGL(flat_store, dim3(blocks), dim3(256), 0, 0, (float4 *)g_out, m); });
+            printf(" | float4 store %.3f ms %.2f TB/s", ms, (double)m * 16 / ms / 1e9);
+            ms = best_ms([&] { hipLaunchKernelGGL(flat_store1, dim3(blocks), dim3(256), 0, 0, g_out, m * 4); });
+            printf(" | dword store %.3f ms %.2f TB/s", ms, (double)m * 16 / ms / 1e9);
+            ms = best_ms([&] { hipLaunchKernelGGL(flat_read, dim3(blocks), dim3(256), 0, 0, (const float4 *)g_out, m, g_in); });
+            printf(" | float4 read %.3f ms %.2f TB/s\n", ms, (double)m * 16 / ms / 1e9);
+            fflush(stdout);
+        }
     }
-    run<1, 1, 0, 0, 4, 13000>(540);
-    run<1, 1, 3, 0, 4, 13000>(540);
-    run<1, 1, 4, 0, 4, 13000>(540);
-    run<1, 1, 0, 38, 4, 13000>(540);
-    run<1, 1, 3, 38, 4, 13000>(540);
-    run<1, 1, 4, 38, 4, 13000>(540);
-    run<1, 1, 0, 0, 4>(540);
-    run<1, 1, 3, 0, 4>(540);
-    run<1, 1, 4, 0, 4>(540);
-    run<1, 1, 3, 0, 4, 13000>(180);
-    run<1, 1, 4, 0, 4, 13000>(180);
+    if (set == 0 || set == 2) { // the pass's own pattern: launch shape, lockstep, resident grid
+        run<1, 1, 0, 0, 4, 13000>(540);
+        run<1, 1, 0, 0, 4, 13000, 1, 0, 1>(540, 3072);
+        run<1, 1, 0, 0, 4, 13000, 1, 0, 1>(540, 2048);
+        run<1, 1, 0, 0, 4, 13000, 1, 0, 1>(540, 1536);
+        run<1, 1, 0, 0, 4, 13000, 1, 0, 1>(540, 1024);
+        run<1, 1, 0, 0, 4, 13000, 1, 0, 1>(1080, 3072);
+        run<1, 1, 0, 0, 4, 13000, 1, 0, 1>(180, 3072);
+        run<2, 1, 0, 0, 4, 13000>(540);
+        run<2, 1, 0, 0, 4, 13000, 1, 0, 1>(540, 3072);
+        run<2, 1, 0, 0, 4, 13000, 1, 0, 1>(540, 2048);
+        run<2, 1, 0, 0, 4, 20000, 1, 0, 1>(540, 2048);
+        run<2, 1, 0, 0, 8, 20000, 1, 0, 1>(540, 2048);
+        // lockstep workgroups: 5, 6, 10 or 15 waves side by side, a barrier per row
+        run<1, 5, 0, 0, 4, 0, 1, 1>(540);
+        run<1, 6, 0, 0, 4, 0, 1, 1>(540);
+        run<1, 6, 0, 0, 4, 0, 1, 0>(540);
+        run<1, 10, 0, 0, 4, 0, 1, 1>(540);
+        run<1, 15, 0, 0, 4, 0, 1, 1>(540);
+        run<1, 15, 0, 0, 4, 0, 1, 0>(540);
+        run<1, 6, 0, 0, 4, 78000, 1, 1>(540);  // two 6-wave workgroups per CU = 3 waves per SIMD
+        run<1, 6, 0, 0, 4, 78000, 1, 1, 1>(540, 512);
+        run<1, 15, 0, 0, 4, 0, 1, 1, 1>(540, 512);
+        run<2, 5, 0, 0, 4, 0, 1, 1>(540);
+        run<2, 15, 0, 0, 4, 0, 1, 1>(540);
+        run<1, 6, 0, 38, 4, 78000, 1, 1>(540);
+        run<1, 1, 0, 38, 4, 13000>(540);
+        run<1, 1, 0, 38, 4, 13000, 1, 0, 1>(540, 3072);
+        run<2, 1, 0, 38, 4, 20000>(540);
+        run<2, 1, 0, 38, 4, 20000, 1, 0, 1>(540, 2048);
+    }
     return 0;
 }
