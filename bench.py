@@ -233,6 +233,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="images per launch set (0 = library default)")
     ap.add_argument("--lanes", type=int, default=0, help="launch sets in flight (0 = library default)")
     ap.add_argument("--strip-rows", type=int, default=0, help="rows per strip of the pyramid pass (0 = chosen per launch)")
+    ap.add_argument("--columns", type=int, default=0, choices=[0, 1, 2],
+                    help="columns per lane of the pyramid pass (0 = library default)")
+    ap.add_argument("--columns-min-width", type=int, default=0, help="narrowest octave that takes two columns per lane")
     ap.add_argument("--dense", action="store_true", help="high keypoint density images")
     ap.add_argument("--queue-cap", type=int, default=-1,
                     help="candidate queue entries per image and scale (0 = dense detector only; -1 = library default)")
@@ -298,6 +301,8 @@ def main():
         sift_amd.lib().sift_set_strip_rows(args.strip_rows)
     if args.queue_cap >= 0:
         sift_amd.lib().sift_set_queue_cap(args.queue_cap)
+    if args.columns:
+        sift_amd.lib().sift_set_pyramid_columns(args.columns, args.columns_min_width)
 
     threads = host_threads()
     config4 = args.mode == "config4"

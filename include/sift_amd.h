@@ -200,6 +200,11 @@ int sift_debug_batch_slot(int n, int i, int *slot, int *image);
 /* rows per strip of the pyramid pass; 0 (default) = chosen per launch from the image
  * size and the number of images.  Results do not depend on it. */
 void sift_set_strip_rows(int rows);
+/* Columns each lane of the pyramid pass owns: 1 (64-column tiles, three waves per SIMD) or 2
+ * (128-column tiles, 512-byte plane stores, two waves per SIMD) for octaves at least min_width
+ * pixels wide (0 keeps the current width limit); the reference profile only.  Results do not
+ * depend on it. */
+void sift_set_pyramid_columns(int cols, int min_width);
 /* launch sets in flight at once, each on a private stream and arena: 1 or 2
  * (default 2: the short kernels of the small octaves of one set overlap the
  * long kernels of the other) */

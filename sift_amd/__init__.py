@@ -75,6 +75,7 @@ SYMBOLS = {
     "sift_noalloc_scratch_bytes": (C.c_size_t, []),
     "sift_quantize_descriptors": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "sift_set_batch_chunk": (None, [C.c_int]),
+    "sift_set_pyramid_columns": (None, [C.c_int, C.c_int]),
     "sift_set_batch_lanes": (None, [C.c_int]),
     "sift_set_queue_cap": (None, [C.c_int]),
     "sift_get_group_counts": (C.c_int, [C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.c_int]),
@@ -210,7 +211,9 @@ def extract_list_multi(paths, dst_dir=None, n_workers=1):
     rc = lib().sift_extract_list_multi(os.fsencode(dst_dir) if dst_dir else None, arr, len(paths), n_workers,
                                        counts.ctypes.data_as(_ip))
     if rc:
-        raise SiftError(last_error() or "sift_extract_list_multi failed")
+        msg = last_error() or "sift_extract_list_multi failed"
+        lib().sift_clear_error()  # the message travels with the exception, not with the next call
+        raise SiftError(msg)
     return counts
 
 

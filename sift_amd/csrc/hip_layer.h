@@ -90,6 +90,8 @@ const char *hl_error_string(int code);
 
 /* rows per strip of the pyramid pass (0 = chosen per launch); for experiments */
 void hl_set_pyramid_strip_rows(int rows);
+/* columns per lane of the pyramid pass: 1, or 2 for octaves at least min_width wide (0 = keep) */
+void hl_set_pyramid_columns(int cols, int min_width);
 
 /* The static device buffer behind the entry point that allocates nothing: the current
  * device's address of it (looked up on the first call per device) and its size. */

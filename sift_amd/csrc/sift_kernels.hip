@@ -63,6 +63,23 @@ __device__ __forceinline__ float2v tap2(const hl_taps &t, int pair, int k)
     const int m = k <= 9 ? k : 18 - k;
     return float2v{t.t[m][2 * pair], t.t[m][2 * pair + 1]};
 }
+// d = tap * b + c on both halves of b and c, the tap being ONE half of the aligned scalar pair that
+// holds planes (2j, 2j+1): the instruction's half selects broadcast it, so a tap costs no scalar
+// register beyond its place in the table (the compiler, left to itself, copies every tap into a
+// scalar pair of its own and runs out of scalar registers).  ZERO: c is 0.
+template <int HI, bool ZERO>
+__device__ __forceinline__ float2v pk_fma_tap(float2v tap_pair, float2v b, float2v c)
+{
+    float2v d;
+    if (ZERO) {
+        if (HI) asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(d) : "s"(tap_pair), "v"(b));
+        else asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(d) : "s"(tap_pair), "v"(b));
+    } else {
+        if (HI) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0]" : "=v"(d) : "s"(tap_pair), "v"(b), "v"(c));
+        else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "s"(tap_pair), "v"(b), "v"(c));
+    }
+    return d;
+}
 // two IEEE fused multiply-adds in one instruction (v_pk_fma_f32)
 __device__ __forceinline__ float2v pk_fma(float2v a, float2v b, float2v c)
 {
@@ -274,8 +291,11 @@ __global__ __launch_bounds__(64) void col_blur_dog_kernel(
 //             and even columns (resizeKernel cudaSiftD.cu:544-559 folded into
 //             the fetch; the down-sampled base is never materialised)
 // ---------------------------------------------------------------------------
-constexpr int FZ_PF = 3;            // source rows in flight per wave (measured: 3 and 4 within 0.5 %, 9 is 5 % slower)
-constexpr int FZ_SLOTS = FZ_PF + 1; // LDS row buffers: the rows in flight and the row being read
+#ifndef PYR_FZ_PF
+#define PYR_FZ_PF 3
+#endif
+constexpr int FZ_PF = PYR_FZ_PF;    // source rows in flight per wave (measured: 3 and 4 within 0.5 %, 9 is 5 % slower)
+constexpr int FZ_SLOTS = FZ_PF == 2 ? 4 : FZ_PF + 1; // LDS row buffers: the rows in flight and the row being read (a divisor of 20)
 static_assert(20 % FZ_SLOTS == 0, "the row buffers must be used in whole turns per row chunk");
 constexpr int FZ_STAGE = 88; // floats staged per row
 // Cache policy of the plane stores: non-temporal, device scope (the "nt" and "sc1" bits).  The planes
@@ -304,7 +324,7 @@ template <int S, int SRC_MODE, bool PLAIN>
 __global__ __launch_bounds__(64, (S == 2 ? PYR_WAVES_S2 : PYR_WAVES_S3)) void pyramid_kernel(
     const float *__restrict__ src, int src_w, int src_h, int src_pitch, long src_stride,
     float *__restrict__ blur, long blur_stride, int w, int p, int h, int rows, hl_taps taps, float contrast, unsigned *__restrict__ queue,
-    long queue_stride, unsigned *__restrict__ qcount, long qcount_stride, int qcap, int group0)
+    long queue_stride, unsigned *__restrict__ qcount, long qcount_stride, int qcap, int group0, int vgx, int vgy, int vgz)
 {
     constexpr int NP = S + 3;
     constexpr bool plain = PLAIN; // the detector without tiles ("lowe" profile)
@@ -320,11 +340,19 @@ __global__ __launch_bounds__(64, (S == 2 ? PYR_WAVES_S2 : PYR_WAVES_S3)) void py
     // L2.  The remap gives every XCD one contiguous run of (column, strip,
     // image) tiles, so the waves that share source lines (neighbouring columns)
     // fetch them through the same L2.  Bijective for any grid size.
+    // (vgx, vgy, vgz) is the grid of tiles.  Normally it is the launch grid.  Experiment
+    // PYR_EXP_PERSIST: the launch is only as many blocks as the chip holds at once (a multiple
+    // of 8, so a block stays on its XCD's run of tiles) and each block walks the tile list.
+    const unsigned nwg = (unsigned)vgx * (unsigned)vgy * (unsigned)vgz;
+#ifdef PYR_EXP_PERSIST
+    for (unsigned orig = blockIdx.x; orig < nwg; orig += gridDim.x) {
+#else
+    {
+        const unsigned orig = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+#endif
     int tile_x, tile_y, tile_z;
     {
-        const unsigned gx = gridDim.x, gy = gridDim.y;
-        const unsigned nwg = gx * gy * gridDim.z;
-        const unsigned orig = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const unsigned gx = (unsigned)vgx, gy = (unsigned)vgy;
         const unsigned q = nwg / 8, r = nwg % 8, xcd = orig % 8;
         const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
         tile_x = (int)(t % gx);
@@ -656,8 +684,260 @@ __global__ __launch_bounds__(64, (S == 2 ? PYR_WAVES_S2 : PYR_WAVES_S3)) void py
         for (int i = 0; i < S; ++i) push(i, __ballot(((pend >> i) | (pend >> (S + i))) & 1u), y1 - 1);
     }
     if (pre) flush();
+    } // tile
 }
 
+
+// ---------------------------------------------------------------------------
+// The same pass with TWO columns per lane: a wave owns 128 columns, lane l the columns
+// x0 + 2l and x0 + 2l + 1.  Every packed FMA then works on the two columns of one plane
+// (the tap is one scalar for both halves), each plane row leaves the wave as one 512-byte
+// store (8 bytes per lane), the apron columns are 18 in 146 instead of 24 in 88, and the
+// per-row overhead (fetch issue, waits, address updates, branches) is paid once per 128
+// pixels.  The price is the ring: 20 slots x (S+3) planes x 2 columns = 200 registers at two
+// scales, so two waves per SIMD instead of three.
+// Results are bit-identical to pyramid_kernel's: the same chains in the same order.
+// Reference profile only (the plain pre-filter needs its neighbours across the two columns).
+// ---------------------------------------------------------------------------
+#ifndef PYR2_FZ_PF
+#define PYR2_FZ_PF 3
+#endif
+constexpr int FZ2_PF = PYR2_FZ_PF;
+constexpr int FZ2_SLOTS = FZ2_PF == 2 ? 4 : FZ2_PF + 1;
+static_assert(20 % FZ2_SLOTS == 0, "the row buffers must be used in whole turns per row chunk");
+constexpr int FZ2_STAGE = 192; // floats per LDS row buffer: three fetch instructions of 64
+constexpr int FZ2_USED = 146;  // staged float j is pixel x0 - 9 + j; the last one a lane reads is 2*63 + 19
+
+template <int S, int SRC_MODE>
+__global__ __launch_bounds__(64, 2) void pyramid2_kernel(
+    const float *__restrict__ src, int src_w, int src_h, int src_pitch, long src_stride,
+    float *__restrict__ blur, long blur_stride, int w, int p, int h, int rows, hl_taps taps, float contrast, unsigned *__restrict__ queue,
+    long queue_stride, unsigned *__restrict__ qcount, long qcount_stride, int qcap, int group0, int vgx, int vgy, int vgz)
+{
+    constexpr int NP = S + 3;
+    __shared__ __attribute__((aligned(16))) float lds[FZ2_SLOTS][FZ2_STAGE];
+    __shared__ unsigned lq[S][PQ_CAP];
+    const int lane = threadIdx.x;
+    const unsigned nwg = (unsigned)vgx * (unsigned)vgy * (unsigned)vgz;
+    const unsigned orig = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    int tile_x, tile_y, tile_z;
+    { // XCD-aware remap, as in pyramid_kernel
+        const unsigned gx = (unsigned)vgx, gy = (unsigned)vgy;
+        const unsigned q = nwg / 8, r = nwg % 8, xcd = orig % 8;
+        const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+        tile_x = (int)(t % gx);
+        tile_y = (int)((t / gx) % gy);
+        tile_z = (int)(t / (gx * gy));
+    }
+    const int x0 = tile_x * 128;
+    const int y0 = tile_y * rows;
+    const int y1 = min(y0 + rows, h);
+    const int nin = (y1 - y0) + 2 * RADIUS;
+    const long plane = (long)p * h;
+    const int z = tile_z;
+    constexpr int ES = SRC_MODE == 1 ? 1 : 4;
+    const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(src) + z * src_stride * ES), 0,
+        (int)(unsigned)min((long)src_pitch * src_h * ES, 0xffffffffL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t bl_rs = __builtin_amdgcn_make_buffer_rsrc(
+        blur + z * blur_stride, 0, (int)(unsigned)min(plane * NP * 4, (long)FZ_DROP), 0x00020000);
+    const int xl = x0 + 2 * lane;                                    // this lane's first column
+    const int out_lane = xl < p ? xl * 4 : (int)FZ_DROP;             // (the pitch is even: both columns or none)
+    unsigned out_row = (unsigned)y0 * p * 4u;
+    const unsigned plane_b = (unsigned)plane * 4u;
+    const bool pre = queue != nullptr;
+    // lanes the detector pre-filter may queue, per column of the lane (cudaSiftD.cu:289; the
+    // middle tile of a 96-wide block never fires)
+    unsigned long long pre_mask[2], pre_mask0[2], alias_a[2], alias_b[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int xq = xl + c;
+        const int xq_tile = (xq % XT_DATAX) / XT_BDIM;
+        const bool pre_lane = xq > 8 && xq < w - 8 && xq_tile != 1;
+        pre_mask[c] = __ballot(pre_lane);
+        pre_mask0[c] = __ballot(pre_lane && xq_tile == 0);
+        const int xta = xq + 37, xtb = xq - 64; // targets of the aliased centre cells, see pyramid_kernel
+        alias_a[c] = __ballot(xq < w && (xta % XT_DATAX) >= 2 * XT_BDIM && xta > 8 && xta < w - 8);
+        alias_b[c] = __ballot(xq < w && xtb > 8 && (xtb % XT_DATAX) < XT_BDIM && xtb < w - 8);
+    }
+    unsigned lq_n[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) lq_n[i] = 0;
+    float thr[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i)
+        thr[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(
+            (pre && qcount[z * qcount_stride + group0 + i] > (unsigned)qcap) ? __builtin_inff() : contrast)));
+
+    // ---- source fetch: lane j fetches staged floats j, 64 + j and (j < 18) 128 + j ----
+    constexpr int SX = SRC_MODE == 2 ? 2 : 1;
+    int col_off[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int xa = x0 - RADIUS + 64 * q + lane;
+        const bool ok = 64 * q + lane < FZ2_USED && xa >= 0 && xa < w;
+        col_off[q] = ok ? SX * xa * ES : (int)FZ_DROP;
+    }
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float *)&lds[0][0];
+    int yi_next = y0 - RADIUS;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    auto fetch = [&](const int slot) __attribute__((always_inline)) {
+        const int yi = yi_next++;
+        const unsigned row = (yi >= 0 && yi < h) ? (unsigned)(SX * yi) * (unsigned)src_pitch * (unsigned)ES : FZ_DROP;
+        const unsigned dst = lds_base + (unsigned)slot * (unsigned)(FZ2_STAGE * 4);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (SRC_MODE == 1)
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_ubyte %1, %2, %3 offen lds" ::"s"(dst + 256u * q), "v"(col_off[q]), "s"(src_rs), "s"(row) : "memory", "m0");
+            else
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(dst + 256u * q), "v"(col_off[q]), "s"(src_rs), "s"(row) : "memory", "m0");
+        }
+    };
+#pragma clang diagnostic pop
+    // vector-memory operations issued between a row's fetch and its first read
+    constexpr int FZ2_WAIT = NP + (NP + 3) * (FZ2_PF - 1) + 3;
+    static_assert(FZ2_WAIT < 64, "the counter holds 63");
+
+    float2v acc[NP][COL_RING]; // [plane][ring slot] = the partial column sums of the lane's two columns
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+#pragma unroll
+        for (int k = 0; k < COL_RING; ++k) acc[i][k] = float2v{0.f, 0.f};
+
+    auto push = [&](const int i, const unsigned long long hits, const int y, const int dx) __attribute__((always_inline)) {
+        if (hits) {
+            const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(hits >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hits, 0u));
+            const unsigned slot = lq_n[i] + below;
+            if (((hits >> lane) & 1ull) && slot < PQ_CAP) lq[i][slot] = (unsigned)(xl + dx) | ((unsigned)y << 16);
+            lq_n[i] += (unsigned)__popcll(hits);
+        }
+    };
+
+    auto chunk = [&](const int rb) __attribute__((always_inline)) {
+        static_for<COL_RING>([&](auto rr_c) __attribute__((always_inline)) {
+            constexpr int rr = decltype(rr_c)::value;
+            const int r = rb + rr;
+            __builtin_amdgcn_sched_barrier(0);
+            if (r >= nin) return;
+            fetch((rr + FZ2_PF) % FZ2_SLOTS);
+            __builtin_amdgcn_s_setprio(0);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FZ2_WAIT) : "memory");
+            constexpr int slot = rr % FZ2_SLOTS;
+            if (SRC_MODE == 1) {
+                unsigned a[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a[q] = __float_as_uint(lds[slot][lane + 64 * q]);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) lds[slot][lane + 64 * q] = (float)a[q];
+                asm volatile("" ::: "memory");
+            }
+            // window value j of the lane is staged float 2*lane + j.  Tap k multiplies (w[k], w[k+1]) for
+            // the lane's two columns: an aligned 8-byte read for even k, two 4-byte reads for odd k.
+            float2v vrow[NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) vrow[i] = float2v{0.f, 0.f};
+            const float *wl = &lds[slot][2 * lane];
+#pragma unroll
+            for (int k = 0; k < TAPS; ++k) {
+                float2v wk;
+                if (k & 1) wk = float2v{wl[k], wl[k + 1]};
+                else wk = *reinterpret_cast<const float2v *>(wl + k);
+                static_for<NP>([&](auto ic) __attribute__((always_inline)) {
+                    constexpr int i = decltype(ic)::value;
+                    if (k == 0) vrow[i] = pk_fma_tap<i & 1, true>(tap2(taps, i / 2, k), wk, vrow[i]);
+                    else vrow[i] = pk_fma_tap<i & 1, false>(tap2(taps, i / 2, k), wk, vrow[i]);
+                });
+            }
+#pragma unroll
+            for (int k = 0; k < TAPS; ++k) {
+                const int slot = (rr - k + COL_RING) % COL_RING;
+                static_for<NP>([&](auto ic) __attribute__((always_inline)) {
+                    constexpr int i = decltype(ic)::value;
+                    if (k == 0) acc[i][slot] = pk_fma_tap<i & 1, true>(tap2(taps, i / 2, k), vrow[i], acc[i][slot]);
+                    else acc[i][slot] = pk_fma_tap<i & 1, false>(tap2(taps, i / 2, k), vrow[i], acc[i][slot]);
+                });
+            }
+            const bool valid = r >= 2 * RADIUS && r < nin; // wave-uniform
+            const int vo = out_lane | (valid ? 0 : (int)FZ_DROP);
+            constexpr int e = (rr - 2 * RADIUS + COL_RING) % COL_RING;
+            float2v b[NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) b[i] = acc[i][e];
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                typedef unsigned u2v __attribute__((ext_vector_type(2)));
+                __builtin_amdgcn_raw_buffer_store_b64(u2v{__float_as_uint(b[i].x), __float_as_uint(b[i].y)}, bl_rs, vo,
+                                                      (int)(out_row + i * plane_b), FZ_STORE_POLICY);
+            }
+            out_row += valid ? (unsigned)p * 4u : 0u;
+            // detector pre-filter, as in pyramid_kernel, once per column of the lane
+            const int yo = y0 + r - 2 * RADIUS;
+            const bool row_ok = pre && valid && yo > 8 && yo < h - 8 && (yo & 31) < 31; // wave-uniform
+            if (row_ok) {
+#pragma unroll
+                for (int i = 0; i < S; ++i) {
+                    const float2v d = float2v{__fsub_rn(b[i + 1].x, b[i + 2].x), __fsub_rn(b[i + 1].y, b[i + 2].y)};
+                    push(i, __ballot(fabsf(d.x) > thr[i]) & ((yo & 31) == 30 ? pre_mask0[0] : pre_mask[0]), yo, 0);
+                    push(i, __ballot(fabsf(d.y) > thr[i]) & ((yo & 31) == 30 ? pre_mask0[1] : pre_mask[1]), yo, 1);
+                }
+            }
+            const int ym = yo & 31;
+            if (pre && valid && (ym == 31 || ym == 0)) { // a source row of the aliased centre cells
+                const int yt = yo + 31;
+                const bool yt_ok = yt > 8 && yt < h - 8, yt1_ok = yt + 1 > 8 && yt + 1 < h - 8;
+#pragma unroll
+                for (int i = 0; i < S; ++i) {
+                    const unsigned long long big0 = __ballot(fabsf(__fsub_rn(b[i + 2].x, b[i + 3].x)) > thr[i]);
+                    const unsigned long long big1 = __ballot(fabsf(__fsub_rn(b[i + 2].y, b[i + 3].y)) > thr[i]);
+                    if (yt_ok) {
+                        push(i, big0 & alias_a[0], yt, 37);
+                        push(i, big1 & alias_a[1], yt, 38);
+                    }
+                    if (ym == 31 && yt1_ok) {
+                        push(i, big0 & alias_b[0], yt + 1, -64);
+                        push(i, big1 & alias_b[1], yt + 1, -63);
+                    }
+                }
+            }
+        });
+    };
+    auto flush = [&]() __attribute__((always_inline)) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const unsigned n = lq_n[i];
+            if (n == 0) continue;
+            unsigned base = 0;
+            if (lane == 0)
+                base = n > PQ_CAP ? (atomicOr(&qcount[z * qcount_stride + group0 + i], 0x80000000u) | 0x80000000u)
+                                  : atomicAdd(&qcount[z * qcount_stride + group0 + i], n);
+            base = __builtin_amdgcn_readfirstlane(__shfl(base, 0));
+            if (n <= PQ_CAP)
+                for (unsigned e = lane; e < n; e += 64)
+                    if (base + e < (unsigned)qcap) queue[z * queue_stride + (long)i * qcap + base + e] = lq[i][e];
+            if (base + n > (unsigned)qcap) thr[i] = __builtin_inff();
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < S; ++i) lq_n[i] = 0;
+    };
+#pragma unroll
+    for (int q = 0; q < FZ2_PF; ++q) fetch(q);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int rb = 0; rb < nin; rb += COL_RING) {
+        chunk(rb);
+        if (pre) { // a chunk of 20 rows adds at most 2560 entries per scale, normally a few
+            unsigned fill = 0;
+#pragma unroll
+            for (int i = 0; i < S; ++i) fill = max(fill, lq_n[i]);
+            if (fill > PQ_CAP / 2) flush();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (pre) flush();
+}
 
 // ---------------------------------------------------------------------------
 // Detection.  The reference's acceptance rule depends on where a pixel sits in
@@ -2297,6 +2577,10 @@ inline int launch_status() { return chk(hipGetLastError()); }
 inline int idivup(int a, int b) { return (a + b - 1) / b; }
 
 int g_strip_override = 0; // > 0: rows per strip of the pyramid pass, for experiments
+// columns per lane of the pyramid pass: 1 = pyramid_kernel; 2 = pyramid2_kernel for octaves at least
+// g_pyr2_min_w wide (reference profile)
+int g_pyr_cols = 1;
+int g_pyr2_min_w = 512;
 
 // Rows per strip of the fused pyramid pass.  A wave walks its strip row by row and needs 18
 // rows of apron, so a strip of r rows costs r + 18 row steps; the waves of a launch run in
@@ -2304,11 +2588,11 @@ int g_strip_override = 0; // > 0: rows per strip of the pyramid pass, for experi
 // rounds x steps per wave is smallest: tall strips when the batch alone fills the chip
 // (1080p, 256 images: 2 strips of 540 rows = 558 steps per column instead of 6 x 198),
 // short ones when a single image has to be spread over all SIMDs.
-int pyramid_strip_rows(int w, int h, int nimg, int n_scales)
+int pyramid_strip_rows(int w, int h, int nimg, int n_scales, int cols_per_lane)
 {
     if (g_strip_override > 0) return g_strip_override < h ? g_strip_override : h;
-    const long slots = 256L * 4 * (n_scales == 2 ? PYR_WAVES_S2 : PYR_WAVES_S3);
-    const long gx = idivup(w, 64);
+    const long slots = 256L * 4 * (cols_per_lane == 2 ? 2 : (n_scales == 2 ? PYR_WAVES_S2 : PYR_WAVES_S3));
+    const long gx = idivup(w, 64 * cols_per_lane);
     long best_t = -1;
     int best_rows = h;
     for (int n = 1; n <= h; ++n) {
@@ -2330,6 +2614,11 @@ int pyramid_strip_rows(int w, int h, int nimg, int n_scales)
 extern "C" {
 
 void hl_set_pyramid_strip_rows(int rows) { g_strip_override = rows; }
+void hl_set_pyramid_columns(int cols, int min_width)
+{
+    g_pyr_cols = cols == 2 ? 2 : 1;
+    if (min_width > 0) g_pyr2_min_w = min_width;
+}
 
 int hl_device_count(void)
 {
@@ -2540,14 +2829,41 @@ int hl_pyramid(const void *src, int src_w, int src_h, int src_pitch, long src_st
     if ((long)p * h * (n_scales + 3) * 4 >= (long)FZ_DROP || (long)src_pitch * src_h * (src_mode == 1 ? 1 : 4) > 0xffffffffL)
         return -1007;
     if (queue && (!qcount || qcap < 1 || w > 65535 || h > 65535)) return -1008;
-    const int rows = pyramid_strip_rows(w, h, nimg, n_scales);
-    dim3 grid(idivup(w, 64), idivup(h, rows), nimg), block(64);
+    if (n_scales != 2 && n_scales != 3) return -1002;
+    if (g_pyr_cols == 2 && !plain && n_scales == 2 && w >= g_pyr2_min_w) { // two columns per lane (its ring needs 200 registers at 2 scales; 3 do not fit)
+        const int rows = pyramid_strip_rows(w, h, nimg, n_scales, 2);
+        const dim3 tiles(idivup(w, 128), idivup(h, rows), nimg), block(64);
+        hipStream_t s = (hipStream_t)stream;
+        ScopedTimer t(4, s);
+#define PYR2_LAUNCH(SS, MD)                                                                         \
+    hipLaunchKernelGGL((pyramid2_kernel<SS, MD>), tiles, block, 0, s, (const float *)src, src_w,    \
+                       src_h, src_pitch, src_stride, blur, blur_stride, w, p, h, rows, *taps,       \
+                       contrast, queue, queue_stride, qcount, qcount_stride, qcap, group0,         \
+                       (int)tiles.x, (int)tiles.y, (int)tiles.z)
+        switch (src_mode) {
+        case 0: PYR2_LAUNCH(2, 0); break;
+        case 1: PYR2_LAUNCH(2, 1); break;
+        default: PYR2_LAUNCH(2, 2); break;
+        }
+#undef PYR2_LAUNCH
+        return launch_status();
+    }
+    const int rows = pyramid_strip_rows(w, h, nimg, n_scales, 1);
+    const dim3 tiles(idivup(w, 64), idivup(h, rows), nimg), block(64);
+#ifdef PYR_EXP_PERSIST
+    const unsigned resident = 256u * 4u * (n_scales == 2 ? PYR_WAVES_S2 : PYR_WAVES_S3);
+    const unsigned total = tiles.x * tiles.y * tiles.z;
+    const dim3 grid(total < resident ? total : resident);
+#else
+    const dim3 grid = tiles;
+#endif
     hipStream_t s = (hipStream_t)stream;
     ScopedTimer t(4, s);
 #define PYR_LAUNCH_P(SS, MD, PL)                                                                   \
     hipLaunchKernelGGL((pyramid_kernel<SS, MD, PL>), grid, block, 0, s, (const float *)src, src_w, \
                        src_h, src_pitch, src_stride, blur, blur_stride, w, p, h, rows, *taps,      \
-                       contrast, queue, queue_stride, qcount, qcount_stride, qcap, group0)
+                       contrast, queue, queue_stride, qcount, qcount_stride, qcap, group0,        \
+                       (int)tiles.x, (int)tiles.y, (int)tiles.z)
 #define PYR_LAUNCH(SS, MD)                                                                         \
     do {                                                                                           \
         if (plain) PYR_LAUNCH_P(SS, MD, true);                                                     \

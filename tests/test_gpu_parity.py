@@ -890,5 +890,6 @@ def test_list_pipeline_on_several_workers_matches_the_pairwise_pipeline(sift, or
             assert filecmp.cmp(base / f, out / f, shallow=False), f"{f} differs with {workers} workers"
     # without a destination only the counts come back
     assert sift.extract_list_multi(paths[:5], None, 2).tolist() == ref_counts[:5]
-    with pytest.raises(sift.SiftError):
+    with pytest.raises(sift.SiftError, match="missing.pgm"):  # the worker thread's message reaches the caller
         sift.extract_list_multi(paths[:2] + [str(tmp_path / "missing.pgm")], None, 1)
+    assert sift.last_error() == ""

@@ -72,6 +72,37 @@ def test_fused_kernel_planes_match_the_oracle(sift, oracle_mod, w, h, S, O, nimg
         sift.set_params()
 
 
+@pytest.mark.parametrize(
+    "w,h,O,nimg,u8,min_w",
+    [(800, 640, 4, 2, False, 1),      # every octave through the two-column kernel, down to 100x80
+     (333, 129, 3, 3, False, 1),      # ragged: a last tile of 77 columns, widths below one tile
+     (1024, 575, 4, 2, True, 1),      # 8-bit source
+     (1920, 1080, 5, 3, False, 512),  # the bench's mix: wide octaves two columns per lane, narrow ones one
+     (130, 40, 2, 1, False, 1)],
+)
+def test_two_columns_per_lane_planes_and_points_match_the_oracle(sift, oracle_mod, w, h, O, nimg, u8, min_w):
+    """pyramid2_kernel (128-column tiles, two columns per lane): the same planes bit for bit, and the
+    same keypoints through its pre-filter's queues."""
+    kw = dict(n_scales=2, n_octaves=O, max_points=20000)
+    sift.set_params(**kw)
+    pr = oracle_mod.params(**kw)
+    sift.lib().sift_set_pyramid_columns(2, min_w)
+    try:
+        imgs = np.stack([sift.synth_image(w, h, seed=8100 + 17 * i + w, dense=bool(i & 1)) for i in range(nimg)])
+        d = torch.from_numpy(imgs.astype(np.uint8) if u8 else imgs).cuda()
+        d_pts, counts = sift.extract_batch(d, w)
+        for i in range(nimg):
+            slot, k = sift.debug_batch_slot(nimg, i)
+            _assert_octaves_equal(sift, oracle_mod, pr, imgs[i], w, slot, k, O, f"two columns {w}x{h} image {i}")
+            ref, _, total = oracle_mod.extract(pr, imgs[i], w)
+            assert total < 20000 and counts[i] == len(ref), f"image {i}: {counts[i]} points, oracle {len(ref)}"
+            got = sift.points_to_numpy(d_pts, int(counts[i]), offset=i * 20000)
+            assert oracle_mod.sort_points(got).tobytes() == oracle_mod.sort_points(ref).tobytes(), f"image {i}"
+    finally:
+        sift.lib().sift_set_pyramid_columns(1, 512)
+        sift.set_params()
+
+
 def test_fused_kernel_planes_through_extractSift_with_a_pitch(sift, oracle_mod):
     """The reference entry point on a pitched image whose pad columns hold garbage."""
     kw = dict(n_scales=2, n_octaves=4, max_points=20000)

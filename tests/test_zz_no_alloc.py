@@ -93,3 +93,43 @@ def test_no_alloc_entry_is_never_timed(sift, oracle_mod):
     assert launches == [0, 0, 0, 0]
     _same(oracle_mod, got, want)
     sift.set_params()
+
+
+def test_no_alloc_entry_runs_under_stream_capture_and_leaves_free_memory_alone(sift, oracle_mod):
+    """The entry's defining property.  After one warm-up call (which looks up the static buffer's
+    address) the call is recorded into a HIP graph: under capture an allocation, an event created
+    for timing or a wait on the stream fails the capture.  The graph is replayed and its points are
+    held to the batch entry's; the device's free memory is the same before and after the calls."""
+    sift.set_params(n_scales=2, n_octaves=4, max_points=2500)
+    w, h = 640, 480
+    img = sift.synth_image(w, h, seed=505, dense=True)
+    want = _batch_entry(sift, img, w)
+    d_img = torch.from_numpy(img).cuda()
+    d_pts = torch.full((2500, sift.POINT_FLOATS), float("nan"), dtype=torch.float32, device="cuda")
+    d_count = torch.full((1,), 777, dtype=torch.int32, device="cuda")
+    args = (C.c_void_p(d_pts.data_ptr()), C.c_void_p(d_count.data_ptr()), C.c_void_p(d_img.data_ptr()), w, w, h)
+    stream = torch.cuda.Stream()
+    assert sift.lib().sift_extract_noalloc(*args, C.c_void_p(stream.cuda_stream)) == 0, sift.last_error()  # warm-up
+    stream.synchronize()
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        assert sift.lib().sift_extract_noalloc(*args, C.c_void_p(stream.cuda_stream)) == 0, sift.last_error()
+    stream.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before, "the entry changed the device's free memory"
+
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        rc = sift.lib().sift_extract_noalloc(*args, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, sift.last_error()
+    d_pts.fill_(float("nan"))
+    d_count.fill_(777)
+    torch.cuda.synchronize()
+    graph.replay()
+    torch.cuda.synchronize()
+    n = int(d_count.item())
+    _same(oracle_mod, sift.points_to_numpy(d_pts, n), want)
+    graph.replay()  # and again: the scratch keeps the last replay's contents
+    torch.cuda.synchronize()
+    _same(oracle_mod, sift.points_to_numpy(d_pts, int(d_count.item())), want)
+    sift.set_params()

@@ -16,6 +16,9 @@ __global__ void k(float *out, const float *tapsg, unsigned long long *cyc, int i
     for (int i = 0; i < 8; ++i) a[i] = f2{(float)i, (float)(threadIdx.x + i)};
     for (int i = 0; i < 16; ++i) s[i] = (float)(threadIdx.x + i);
     f2 v = f2{tapv, tapv + 1.f};
+    double d[8];
+    for (int i = 0; i < 8; ++i) d[i] = (double)(threadIdx.x + i) + 0.5;
+    const double dv = (double)tapv;
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
         if (MODE == 0) { // 16 independent scalar fma, SGPR tap
@@ -27,15 +30,22 @@ __global__ void k(float *out, const float *tapsg, unsigned long long *cyc, int i
         } else if (MODE == 2) { // 8 packed fma, all VGPR
 #pragma unroll
             for (int i = 0; i < 8; ++i) a[i] = __builtin_elementwise_fma(v, v, a[i]);
-        } else { // 8 packed fma, SGPR pair tap, splat of one scalar VGPR (op_sel)
+        } else if (MODE == 3) { // 8 packed fma, SGPR pair tap, splat of one scalar VGPR (op_sel)
 #pragma unroll
             for (int i = 0; i < 8; ++i) a[i] = __builtin_elementwise_fma(f2{ts0, ts1}, f2{tapv, tapv}, a[i]);
+        } else if (MODE == 4) { // 8 independent double-precision fma
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d[i] = __builtin_fma((double)ts0, dv, d[i]);
+        } else { // 4 independent double-precision divisions (correctly rounded: the compiler's expansion)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d[i] = d[i + 4] / (d[i] + dv);
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float r = 0;
     for (int i = 0; i < 8; ++i) r += a[i].x + a[i].y;
     for (int i = 0; i < 16; ++i) r += s[i];
+    for (int i = 0; i < 8; ++i) r += (float)d[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
@@ -82,6 +92,8 @@ int main()
         run<1>("v_pk_fma_f32 sgpr pair", w, 8);
         run<2>("v_pk_fma_f32 vgpr", w, 8);
         run<3>("v_pk_fma_f32 sgpr x splat", w, 8);
+        run<4>("v_fma_f64", w, 8);
+        run<5>("f64 division (whole sequence)", w, 4);
     }
     return 0;
 }
