@@ -175,6 +175,12 @@ void sift_set_batch_chunk(int images_per_launch);
  * 4096).  A queue that overflows is redone by the dense detector, so results do
  * not depend on n; 0 disables the queues (dense detector only). */
 void sift_set_queue_cap(int n);
+/* Launch sets of at most this many first-octave pixels (images x width x height; default
+ * 2,200,000: one 1080p image) skip the queues and run the dense detector alone, which is
+ * the faster route when every kernel of the set is a single round of waves (one image at a
+ * time through extractSift).  0: never.  Results do not depend on it.  No counterpart in
+ * the reference. */
+void sift_set_dense_route_pixels(long pixels);
 /* Diagnostics: after the work of slot streamIdx has completed (it is waited
  * for), copies per (octave, scale) group, octave-major, the number of keypoints
  * the group produced (before the cap) into accepted[] and the number of

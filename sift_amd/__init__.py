@@ -78,6 +78,7 @@ SYMBOLS = {
     "sift_set_pyramid_columns": (None, [C.c_int, C.c_int]),
     "sift_set_batch_lanes": (None, [C.c_int]),
     "sift_set_queue_cap": (None, [C.c_int]),
+    "sift_set_dense_route_pixels": (None, [C.c_long]),
     "sift_get_group_counts": (C.c_int, [C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.c_int]),
     "sift_debug_read_planes": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, C.c_long, _ip, _ip, _ip]),
     "sift_debug_batch_slot": (C.c_int, [C.c_int, C.c_int, _ip, _ip]),

@@ -48,6 +48,9 @@ typedef struct {
      * destroys them afterwards (sift.cu:96,130), so a stored handle would dangle. */
     void *done;
     int busy; /* done has been recorded and not yet waited for */
+    /* batch lanes: 1 + the index of the library's private stream that recorded `done` last,
+     * 0 when it was a caller's stream (work on that private stream needs no wait) */
+    int on_lane;
 } slot_ctx;
 
 /* g_mu guards the building of the tables; g_dev_mu[d] guards device d's slots, batch
@@ -89,6 +92,13 @@ static struct {
 } g_last_batch[MAX_DEV];
 static int g_chunk = 256;
 static int g_queue_cap = QUEUE_CAP; /* 0: no pre-filter, dense detector only */
+/* A launch set of at most this many pixels (images x width x height of the first octave) is
+ * detected by the dense detector alone: its kernels are one round of waves, so the pre-filter's
+ * per-wave start (a counter read) and end (an atomic and a dependent store) sit on every
+ * pyramid launch's critical path, and candidate verification plus the gated dense launch cost
+ * what the dense detector costs by itself at this size.  Measured on one 1080p image: 141 us
+ * against 155 us for the whole call sequence.  0: never. */
+static long g_dense_route_px = 2200000;
 static __thread char g_err[512] = ""; /* the calling thread's last error */
 
 static void set_err(const char *fmt, ...)
@@ -272,6 +282,12 @@ void sift_set_queue_cap(int n)
 {
     if (n >= 0 && n <= (1 << 24))
         g_queue_cap = n;
+}
+
+void sift_set_dense_route_pixels(long px)
+{
+    if (px >= 0)
+        g_dense_route_px = px;
 }
 
 void sift_set_batch_chunk(int n)
@@ -488,7 +504,8 @@ static int enqueue_extract(slot_ctx *c, SiftPoint *pts, unsigned char *meta, con
     float *A = c->arena;
     const long AS = c->arena_stride;
     unsigned *queued = c->counts + HL_MAX_GROUPS; /* second half of each image's counter block */
-    const int prefilter = c->queue_cap > 0;
+    const long set_px = (long)nimg * c->ow[0] * c->oh[0];
+    const int prefilter = c->queue_cap > 0 && set_px > g_dense_route_px;
     hl_detect_args da;
     memset(&da, 0, sizeof da);
     da.n_scales = S;
@@ -585,6 +602,7 @@ static int enqueue_extract(slot_ctx *c, SiftPoint *pts, unsigned char *meta, con
         r = hl_event_record(c->done, stream);
         if (r) return fail_hl(r, "recording slot event");
         c->busy = 1;
+        c->on_lane = 0; /* (the batch entry sets it when the stream was one of its own) */
     }
     return 0;
 }
@@ -966,27 +984,45 @@ static int extract_batch(SiftPoint *d_pts, unsigned char *d_meta, int *h_counts,
         }
         unsigned *bc = d_counts ? d_counts : g_batch_count[dev];
         unsigned *hc = h_counts ? g_host_count[dev] : NULL;
-        /* fork: the private streams start after everything queued on the caller's stream */
-        int r = hl_event_record(g_lane_event[dev][N_LANES], stream);
-        for (int l = 0; l < lanes && !r; ++l)
-            r = hl_stream_wait_event(g_lane_stream[dev][(lane0 + l) % g_lanes], g_lane_event[dev][N_LANES]);
-        if (r) {
-            fail_hl(r, "starting batch streams");
-            break;
+        /* A blocking call of one launch set has nothing to run beside: it goes on the caller's
+         * stream as it is, without the fork to a private stream and the join back (two
+         * cross-stream waits: 60 us of a one-image call, 1 % of a step of 256 1080p images). */
+        const int direct = h_counts && n_sets == 1;
+        int r = 0;
+        if (!direct) {
+            /* fork: the private streams start after everything queued on the caller's stream */
+            r = hl_event_record(g_lane_event[dev][N_LANES], stream);
+            for (int l = 0; l < lanes && !r; ++l)
+                r = hl_stream_wait_event(g_lane_stream[dev][(lane0 + l) % g_lanes], g_lane_event[dev][N_LANES]);
+            if (r) {
+                fail_hl(r, "starting batch streams");
+                break;
+            }
         }
         const int cap = g_params.max_points;
         for (int k = 0; k < n_sets && !bad; ++k) {
             const int i0 = k * chunk;
             const int m = (n - i0) < chunk ? (n - i0) : chunk;
             const int l = (lane0 + k) % g_lanes;
-            bad = enqueue_extract(&g_slots[dev][BATCH_SLOT + l], d_pts + (long)i0 * cap,
-                                  d_meta ? d_meta + 2L * i0 * cap : NULL,
+            slot_ctx *c = &g_slots[dev][BATCH_SLOT + l];
+            void *st = direct ? stream : g_lane_stream[dev][l];
+            /* the arena's previous launch set ran on this lane's private stream (then stream
+             * order is enough) or on some caller's stream (then its event is waited for) */
+            if (c->busy && (direct || c->on_lane != 1 + l)) {
+                r = hl_stream_wait_event(st, c->done);
+                if (r) {
+                    fail_hl(r, "ordering behind the arena's previous launch set");
+                    bad = 1;
+                    break;
+                }
+            }
+            bad = enqueue_extract(c, d_pts + (long)i0 * cap, d_meta ? d_meta + 2L * i0 * cap : NULL,
                                   (const char *)d_imgs + (long)i0 * img_stride * esz, imgs_u8,
-                                  img_stride, m, pitch, 0, bc + i0, 1, hc ? hc + i0 : NULL,
-                                  g_lane_stream[dev][l]);
+                                  img_stride, m, pitch, 0, bc + i0, 1, hc ? hc + i0 : NULL, st);
+            if (!bad && !direct) c->on_lane = 1 + l;
         }
         /* join: the caller's stream continues after both private streams */
-        for (int q = 0; q < lanes; ++q) {
+        for (int q = 0; q < lanes && !direct; ++q) {
             const int l = (lane0 + q) % g_lanes;
             int r2 = hl_event_record(g_lane_event[dev][l], g_lane_stream[dev][l]);
             if (!r2) r2 = hl_stream_wait_event(stream, g_lane_event[dev][l]);

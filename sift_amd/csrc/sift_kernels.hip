@@ -2583,16 +2583,48 @@ int g_pyr_cols = 1;
 int g_pyr2_min_w = 512;
 
 // Rows per strip of the fused pyramid pass.  A wave walks its strip row by row and needs 18
-// rows of apron, so a strip of r rows costs r + 18 row steps; the waves of a launch run in
-// rounds of as many as the chip holds at once.  The strips are cut (equal heights) so that
-// rounds x steps per wave is smallest: tall strips when the batch alone fills the chip
-// (1080p, 256 images: 2 strips of 540 rows = 558 steps per column instead of 6 x 198),
-// short ones when a single image has to be spread over all SIMDs.
+// rows of apron, so a strip of r rows costs r + 18 row steps.
+// A launch larger than the chip holds at once runs in rounds of resident waves, and its time is
+// rounds x steps per wave: tall strips when the batch alone fills the chip (1080p, 256 images:
+// 2 strips of 540 rows = 558 steps per column instead of 6 x 198).
+// A launch the chip holds at once (one image, the small octaves of a few) is a single round, and
+// the time of a row step grows with the waves that share a SIMD: measured on MI355X over the five
+// octaves of one 1080p image and strips of 1 to 32 rows, a step costs 0.45 us when the wave has
+// its SIMD to itself and 0.19 us more per further wave per SIMD (1.02 us with all three resident).
+// So fewer, taller strips than "as many waves as fit" are faster there: 16 rows instead of 11 for
+// one 1080p image (28 against 31 us), 8 instead of 3 for its second octave (20 against 23 us).
+// Costs are kept in units of 0.01 us per step.
+int pyramid_strip_rows_search(int w, int h, int nimg, int n_scales, int cols_per_lane);
+
+// The search walks up to h candidates (13 us of host time for the five octaves of a 1080p image,
+// in front of the first launch of a call that takes 130 us in all): each host thread remembers
+// its last answers.
 int pyramid_strip_rows(int w, int h, int nimg, int n_scales, int cols_per_lane)
 {
     if (g_strip_override > 0) return g_strip_override < h ? g_strip_override : h;
+    struct Memo {
+        int w, h, nimg, n_scales, cols, rows;
+    };
+    constexpr int N = 16;
+    thread_local Memo memo[N] = {};
+    thread_local int next = 0;
+    for (int i = 0; i < N; ++i) {
+        const Memo &m = memo[i];
+        if (m.rows > 0 && m.w == w && m.h == h && m.nimg == nimg && m.n_scales == n_scales && m.cols == cols_per_lane)
+            return m.rows;
+    }
+    const int rows = pyramid_strip_rows_search(w, h, nimg, n_scales, cols_per_lane);
+    memo[next] = Memo{w, h, nimg, n_scales, cols_per_lane, rows};
+    next = (next + 1) % N;
+    return rows;
+}
+
+int pyramid_strip_rows_search(int w, int h, int nimg, int n_scales, int cols_per_lane)
+{
     const long slots = 256L * 4 * (cols_per_lane == 2 ? 2 : (n_scales == 2 ? PYR_WAVES_S2 : PYR_WAVES_S3));
+    const long simds = 256L * 4;
     const long gx = idivup(w, 64 * cols_per_lane);
+    // rounds x steps
     long best_t = -1;
     int best_rows = h;
     for (int n = 1; n <= h; ++n) {
@@ -2605,6 +2637,17 @@ int pyramid_strip_rows(int w, int h, int nimg, int n_scales, int cols_per_lane)
         const long t = rounds * steps;
         if (best_t < 0 || t < best_t) best_t = t, best_rows = rows;
         if (rounds > 64) break; // more strips only add apron rows from here on
+    }
+    if (gx * idivup(h, best_rows) * nimg > slots) return best_rows;
+    // a single round: steps x the cost of a step at that many waves per SIMD
+    best_t = -1;
+    for (int n = 1; n <= h; ++n) {
+        const int rows = idivup(h, n);
+        if (n > 1 && rows == idivup(h, n - 1)) continue;
+        const long waves = gx * idivup(h, rows) * nimg;
+        if (waves > slots) break;
+        const long t = (rows + 2 * RADIUS) * (45 + 19 * waves / simds);
+        if (best_t < 0 || t < best_t) best_t = t, best_rows = rows;
     }
     return best_rows;
 }
@@ -2792,7 +2835,7 @@ int hl_col_blur_dog(const float *tmp, long tmp_stride, float *blur, long blur_st
     // strips give small octaves enough waves to cover the chip.
     int m = 6;
     while (m > 2 && (long)idivup(w, 64) * idivup(h, COL_RING * m - 2 * RADIUS) * nimg < 2048) --m;
-    const int rows = COL_RING * m - 2 * RADIUS;
+    const int rows = g_strip_override > 0 ? (g_strip_override < h ? g_strip_override : h) : COL_RING * m - 2 * RADIUS;
     dim3 grid(idivup(w, 64), idivup(h, rows), nimg), block(64);
     hipStream_t s = (hipStream_t)stream;
     ScopedTimer t(1, s);

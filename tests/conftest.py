@@ -25,4 +25,11 @@ def sift():
     import sift_amd
 
     sift_amd.lib()
+    # The suite runs the queue route (pre-filter, candidate verification) whatever the size of the
+    # job; tests of the dense route that small jobs take by default switch it on themselves.
+    sift_amd.lib().sift_set_dense_route_pixels(0)
     return sift_amd
+
+
+# sift_set_dense_route_pixels' default (include/sift_amd.h)
+DENSE_ROUTE_DEFAULT = 2200000

@@ -60,15 +60,33 @@ def test_pyramid_stages_on_random_shapes(sift, oracle_mod):
     sift.set_params()
 
 
+DENSE_ROUTE_DEFAULT = 2200000  # sift_set_dense_route_pixels' default (include/sift_amd.h)
+
+
 def _extract_gpu(sift, img_host, w):
+    """One image through the reference's call sequence, twice: by the queue route (pre-filter in the
+    pyramid pass, candidate verification) and by the route the library takes by default for a job
+    this small (dense detector alone).  The two must give the same points."""
+    import oracle
+
     h, pitch = img_host.shape
     d_img = torch.from_numpy(np.nan_to_num(img_host, nan=-1e30)).cuda()
-    pts = sift.new_point_buffer()
-    sift.initDeviceConstant()
-    sift.initDeviceVariables()
-    sift.extractSift(pts, d_img, w, pitch, h, None, 0, 0)
-    n = sift.getPointCount(0)
-    return sift.points_to_numpy(pts, n)
+    outs = []
+    try:
+        for route in (DENSE_ROUTE_DEFAULT, 0):
+            sift.lib().sift_set_dense_route_pixels(route)
+            pts = sift.new_point_buffer()
+            sift.initDeviceConstant()
+            sift.initDeviceVariables()
+            sift.extractSift(pts, d_img, w, pitch, h, None, 0, 0)
+            n = sift.getPointCount(0)
+            outs.append(sift.points_to_numpy(pts, n))
+    finally:
+        sift.lib().sift_set_dense_route_pixels(0)
+    if sift.get_params().max_points > max(len(o) for o in outs):  # (over the cap the survivors are any subset)
+        assert oracle.sort_points(outs[0]).tobytes() == oracle.sort_points(outs[1]).tobytes(), \
+            "dense route and queue route disagree"
+    return outs[1]
 
 
 def _assert_points_equal(oracle_mod, got, ref):
@@ -893,3 +911,38 @@ def test_list_pipeline_on_several_workers_matches_the_pairwise_pipeline(sift, or
     with pytest.raises(sift.SiftError, match="missing.pgm"):  # the worker thread's message reaches the caller
         sift.extract_list_multi(paths[:2] + [str(tmp_path / "missing.pgm")], None, 1)
     assert sift.last_error() == ""
+
+
+def test_small_jobs_take_the_dense_route(sift, oracle_mod):
+    """A launch set of at most sift_set_dense_route_pixels() first-octave pixels (default: one
+    1080p image) skips the candidate queues and runs the dense detector alone; larger sets queue.
+    Seen through the queue counters of the slot; the points equal the oracle's either way, also
+    for a batch cut so that some launch sets are small and some are not."""
+    pr = _params(sift, oracle_mod, n_scales=2, n_octaves=4, max_points=20000)
+    w, h = 640, 480
+    img = sift.synth_image(w, h, seed=77, dense=True)
+    ref, _, _ = oracle_mod.extract(pr, img, w)
+    d = torch.from_numpy(img).cuda()
+    L = sift.lib()
+    try:
+        for route, queues in ((DENSE_ROUTE_DEFAULT, False), (w * h - 1, True), (w * h, False), (0, True)):
+            L.sift_set_dense_route_pixels(route)
+            pts = sift.new_point_buffer()
+            sift.initDeviceVariables()
+            sift.extractSift(pts, d, w, w, h, None, 0, 0)
+            n = sift.getPointCount(0)
+            _assert_points_equal(oracle_mod, sift.points_to_numpy(pts, n), ref)
+            acc, queued = sift.group_counts(0)
+            assert sum(acc) == n
+            assert (sum(queued) > 0) == queues, f"route limit {route}: queued {queued}"
+        # batch of 5 in launch sets of 2: sets of 2 images (over the limit below) and a last set of 1 (under it)
+        imgs = np.stack([sift.synth_image(w, h, seed=80 + i, dense=True) for i in range(5)])
+        refs = [oracle_mod.extract(pr, im, w)[0] for im in imgs]
+        L.sift_set_dense_route_pixels(w * h + 1)
+        L.sift_set_batch_chunk(2)
+        got, counts = sift.extract_batch(torch.from_numpy(imgs).cuda(), w)
+        for i in range(5):
+            _assert_points_equal(oracle_mod, sift.points_to_numpy(got, int(counts[i]), offset=i * pr.max_points), refs[i])
+    finally:
+        L.sift_set_dense_route_pixels(0)
+        L.sift_set_batch_chunk(256)
