@@ -67,6 +67,7 @@ SYMBOLS = {
     "sift_set_last_error": (None, [C.c_char_p]),
     "sift_get_tables": (None, [_fp, _fp, _fp]),
     "sift_shutdown": (None, []),
+    "sift_release_arenas": (C.c_int, []),
     "sift_extract_batch": (C.c_int, [_vp, _vp, _ip, _vp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "sift_extract_batch_u8": (C.c_int, [_vp, _vp, _ip, _vp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "sift_extract_batch_async": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int,

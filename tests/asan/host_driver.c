@@ -322,6 +322,27 @@ int main(int argc, char **argv)
     CHECK(sift_extract_list_multi(tmp, list, 0, 1, NULL) == 0);
     CHECK(sift_list_partition(13, 4) == 1);
 
+    /* arenas given back and planned afresh: stream slots and batch lanes, blocking (the caller's
+     * stream) and non-blocking (the private streams) calls in turn on one lane's arena, and the
+     * two detection routes (a one-set job under the pixel limit skips the queues) */
+    CHECK(sift_release_arenas() == 0);
+    CHECK(sift_debug_batch_slot(n, 5, &slot, &image) != 0);
+    sift_clear_error();
+    extractSift(d_pts, d_img, 640, pitch, 400, NULL, 2, 0);
+    CHECK(getPointCount(2) >= 0 && sift_last_error()[0] == 0);
+    for (long lim = 0; lim <= 4000000; lim += 4000000) {
+        sift_set_dense_route_pixels(lim);
+        CHECK(sift_extract_batch(d_bpts, NULL, counts, d_batch, (long)w * h, n, w, w, h, NULL) == 0);
+        CHECK(sift_extract_batch_async(d_bpts, NULL, d_counts, d_batch, 0, (long)w * h, n, w, w, h, NULL) == 0);
+        CHECK(sift_extract_batch(d_bpts, NULL, counts, d_batch, (long)w * h, n, w, w, h, NULL) == 0);
+        CHECK(sift_extract_batch_async(d_bpts, NULL, d_counts, d_batch, 0, (long)w * h, n, w, w, h, NULL) == 0);
+        CHECK(sift_extract_batch_async(d_bpts, NULL, d_counts, d_batch, 0, (long)w * h, n, w, w, h, NULL) == 0);
+        CHECK(sift_extract_batch(d_bpts, NULL, counts, d_batch, (long)w * h, n, w, w, h, NULL) == 0);
+    }
+    sift_set_dense_route_pixels(2200000);
+    CHECK(sift_release_arenas() == 0);
+    CHECK(sift_release_arenas() == 0); /* nothing left to free */
+
     /* two host threads, one per pretend device */
     pthread_t th[3];
     for (intptr_t d = 0; d < 2; ++d) pthread_create(&th[d], NULL, device_thread, (void *)d);

@@ -251,3 +251,42 @@ def test_host_code_under_thread_sanitizer():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "host driver finished" in r.stdout
     assert "WARNING: ThreadSanitizer" not in r.stderr
+
+
+def test_the_integration_notes_binding_compiles_and_links(sift, tmp_path):
+    """The C++ stub INTEGRATION.md gives a maintainer of Sift/src (a header in place of
+    cudaSiftH.h, Sift/src/cudaSiftH.h:6-30) is taken from the notes as it stands and compiled
+    together with a caller shaped like the reference's loop (Sift/src/sift.cu:94-130: one stream
+    per queued image passed by reference, initDeviceConstant / initDeviceVariables every round,
+    extractSift per image, getPointCount as the synchronisation point), then linked against the
+    shipped library.  Nothing is run: no GPU here."""
+    notes = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"```cpp\n(// sift_amd_shim\.h.*?)```", notes, flags=re.S)
+    assert m, "the shim header is missing from INTEGRATION.md"
+    (tmp_path / "sift_amd_shim.h").write_text(m.group(1))
+    (tmp_path / "caller.cc").write_text(r"""
+#include "sift_amd_shim.h"
+#include <cstdio>
+static_assert(sizeof(SiftPoint) == 528, "Sift/src/sift.h:7-13");
+int run_pair(float *d_img[2], SiftPoint *d_pts[2], int w, int pitch, int h)
+{
+    hipStream_t stream[2];
+    for (int i = 0; i < 2; ++i) if (hipStreamCreate(&stream[i]) != hipSuccess) return -1;
+    initDeviceConstant();
+    initDeviceVariables();
+    for (int i = 0; i < 2; ++i) extractSift(d_pts[i], d_img[i], w, pitch, h, stream[i], i, 0);
+    int total = 0;
+    for (int i = 0; i < 2; ++i) total += getPointCount(i) - 1;
+    for (int i = 0; i < 2; ++i) hipStreamDestroy(stream[i]);
+    if (*sift_last_error()) std::fprintf(stderr, "%s\n", sift_last_error());
+    return total;
+}
+int main() { return 0; }
+""")
+    lib_dir = os.path.dirname(sift.LIB_PATH)
+    cmd = ["g++", "-std=c++11", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+           "-I", "/opt/rocm/include", str(tmp_path / "caller.cc"), "-o", str(tmp_path / "caller"),
+           "-L", lib_dir, "-lsift_amd", "-L", "/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]

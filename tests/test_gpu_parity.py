@@ -946,3 +946,37 @@ def test_small_jobs_take_the_dense_route(sift, oracle_mod):
     finally:
         L.sift_set_dense_route_pixels(0)
         L.sift_set_batch_chunk(256)
+
+
+def test_release_arenas_gives_the_memory_back(sift, oracle_mod):
+    """sift_release_arenas frees the planes, queues and lists of the stream slots and batch lanes
+    (the reference frees its planes inside every call, cudaSiftH.cu:58, 172-177; here they are
+    kept between calls): the device's free memory rises by what a batch had taken, and the next
+    calls plan afresh and give the same points."""
+    pr = _params(sift, oracle_mod, n_scales=2, n_octaves=4, max_points=3000)
+    w, h, n = 640, 480, 24
+    imgs = np.stack([sift.synth_image(w, h, seed=500 + i, dense=True) for i in range(n)])
+    d = torch.from_numpy(imgs).cuda()
+    ref0 = oracle_mod.extract(pr, imgs[0], w)[0]
+    assert sift.lib().sift_release_arenas() == 0
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    pts, counts = sift.extract_batch(d, w)
+    first = [oracle_mod.sort_points(sift.points_to_numpy(pts, int(counts[i]), offset=i * pr.max_points)).tobytes()
+             for i in range(n)]
+    one = _extract_gpu(sift, imgs[0], w)
+    _assert_points_equal(oracle_mod, one, ref0)
+    torch.cuda.synchronize()
+    held = free0 - torch.cuda.mem_get_info()[0]
+    assert held > n * w * h * 4 * 5  # at least the first octave's five planes per image (plus what torch took for pts)
+    del pts
+    assert sift.lib().sift_release_arenas() == 0
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    assert torch.cuda.mem_get_info()[0] > free0 - held // 8
+    assert sift.getPointCount(0) == len(ref0)  # the counters outlive the arenas
+    pts, counts = sift.extract_batch(d, w)
+    again = [oracle_mod.sort_points(sift.points_to_numpy(pts, int(counts[i]), offset=i * pr.max_points)).tobytes()
+             for i in range(n)]
+    assert again == first
+    assert first[0] == oracle_mod.sort_points(ref0).tobytes()

@@ -53,6 +53,10 @@ for case in range(cases):
         pr = oracle.params(**kw)
         ref, _, total = oracle.extract(pr, buf, w)
         sift.lib().sift_set_queue_cap(qcap)
+        # launch sets up to this many pixels skip the queues: never, always, or around this job's own size
+        dense_px = int(rng.choice([0, 0, 2200000, w * h, 3 * w * h]))
+        desc["dense_px"] = dense_px
+        sift.lib().sift_set_dense_route_pixels(dense_px)
         route = int(rng.integers(0, 3))  # the single-image entry, the batch entry, the 8-bit batch entry
         if route == 2 and kind == 3:
             route = 1  # the 8-bit entry needs integer pixels
@@ -93,6 +97,7 @@ for case in range(cases):
     if case % 20 == 19:
         print(f"{case + 1} cases, {bad} bad, {time.time() - t0:.0f} s", flush=True)
 sift.lib().sift_set_queue_cap(65536)
+sift.lib().sift_set_dense_route_pixels(2200000)
 sift.lib().sift_set_batch_chunk(256)
 print("done:", cases, "cases,", bad, "bad")
 sys.exit(1 if bad else 0)
