@@ -217,6 +217,12 @@ void sift_set_strip_rows(int rows);
  * pixels wide (0 keeps the current width limit); the reference profile only.  Results do not
  * depend on it. */
 void sift_set_pyramid_columns(int cols, int min_width);
+/* Pyramid launches the chip holds in a single round of waves and that feed no candidate queue
+ * (one image at a time on the dense route, blurOctave) deal the S+3 planes over waves, one plane
+ * per wave (pyramid_plane_kernel): a fifth of the arithmetic per row step and five times the
+ * waves, for calls whose time is the sum of their launches' longest waves.  on = 0 keeps the
+ * one-wave-per-tile kernel for them too (default 1).  Results do not depend on it. */
+void sift_set_pyramid_split(int on);
 /* launch sets in flight at once, each on a private stream and arena: 1 or 2
  * (default 2: the short kernels of the small octaves of one set overlap the
  * long kernels of the other) */

@@ -90,6 +90,9 @@ const char *hl_error_string(int code);
 
 /* rows per strip of the pyramid pass (0 = chosen per launch); for experiments */
 void hl_set_pyramid_strip_rows(int rows);
+/* 0: single-round launches without a candidate queue keep pyramid_kernel (default 1: the planes
+ * are dealt over waves, pyramid_plane_kernel) */
+void hl_set_pyramid_split(int on);
 /* columns per lane of the pyramid pass: 1, or 2 for octaves at least min_width wide (0 = keep) */
 void hl_set_pyramid_columns(int cols, int min_width);
 

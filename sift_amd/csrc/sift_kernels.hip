@@ -689,6 +689,155 @@ __global__ __launch_bounds__(64, (S == 2 ? PYR_WAVES_S2 : PYR_WAVES_S3)) void py
 
 
 // ---------------------------------------------------------------------------
+// The same pass with the planes dealt over waves: a wave owns 64 columns of ONE blur plane.
+// For launches the chip holds in a single round (one image at a time through extractSift,
+// the small octaves of a few images), where a call's time is the sum of its launches'
+// longest waves: a wave of pyramid_kernel needs 0.45 us per row step when it has its SIMD to
+// itself (190 FMAs in chains of 19, its window's LDS reads, the counted wait), this one a
+// fraction of that (38 FMAs), and S+3 times as many waves spread over the SIMDs.  The source
+// row is staged once per wave (S+3 times per tile: the copies after the first come from L2),
+// so this is not the kernel for a batch.  The window of the next row is read from LDS before
+// the chains of the current one run, which hides the LDS latency a lone wave cannot hide.
+// No detector pre-filter: launch sets this small are detected by the dense detector alone.
+// Results are bit-identical to pyramid_kernel's: the same chains in the same order.
+// ---------------------------------------------------------------------------
+#ifndef PYRP_FZ_PF
+#define PYRP_FZ_PF 4
+#endif
+constexpr int FZP_PF = PYRP_FZ_PF;       // source rows in flight per wave
+constexpr int FZP_SLOTS = FZP_PF + 1;    // LDS row buffers (a divisor of 20)
+static_assert(20 % FZP_SLOTS == 0 && FZP_PF >= 2, "the row buffers must be used in whole turns per row chunk");
+#ifndef PYRP_STORE_POLICY
+#define PYRP_STORE_POLICY 0 // the planes of a small launch set are read again at once: let the caches keep them
+#endif
+
+template <int SRC_MODE>
+__global__ __launch_bounds__(64) void pyramid_plane_kernel(
+    const float *__restrict__ src, int src_w, int src_h, int src_pitch, long src_stride,
+    float *__restrict__ blur, long blur_stride, int w, int p, int h, int rows, int np, hl_taps taps,
+    int vgx, int vgy, int vgz)
+{
+    __shared__ float lds[FZP_SLOTS][128];
+    const int lane = threadIdx.x;
+    // XCD-aware remap as in pyramid_kernel; the plane is the fastest index, so the np waves that
+    // stage the same source rows run on one XCD (one L2) side by side
+    const unsigned nwg = (unsigned)vgx * (unsigned)vgy * (unsigned)vgz * (unsigned)np;
+    const unsigned orig = blockIdx.x;
+    int tile_x, tile_y, tile_z, pl;
+    {
+        const unsigned gx = (unsigned)vgx, gy = (unsigned)vgy, n = (unsigned)np;
+        const unsigned q = nwg / 8, r = nwg % 8, xcd = orig % 8;
+        const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+        pl = (int)(t % n);
+        tile_x = (int)((t / n) % gx);
+        tile_y = (int)((t / (n * gx)) % gy);
+        tile_z = (int)(t / (n * gx * gy));
+    }
+    const int x0 = tile_x * 64;
+    const int y0 = tile_y * rows;
+    const int y1 = min(y0 + rows, h);
+    const int nin = (y1 - y0) + 2 * RADIUS;
+    const long plane = (long)p * h;
+    const int z = tile_z;
+    constexpr int ES = SRC_MODE == 1 ? 1 : 4;
+    const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(src) + z * src_stride * ES), 0,
+        (int)(unsigned)min((long)src_pitch * src_h * ES, 0xffffffffL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t bl_rs = __builtin_amdgcn_make_buffer_rsrc(
+        blur + z * blur_stride, 0, (int)(unsigned)min(plane * np * 4, (long)FZ_DROP), 0x00020000);
+    const int out_lane = (x0 + lane) * 4;
+    unsigned out_row = (unsigned)y0 * p * 4u + (unsigned)pl * (unsigned)plane * 4u; // the next completed row of this wave's plane
+    // this plane's ten distinct taps (wave-uniform: scalar registers)
+    float c[HL_HALF_TAPS];
+#pragma unroll
+    for (int m = 0; m < HL_HALF_TAPS; ++m)
+        c[m] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(taps.t[m][pl])));
+    auto tapk = [&](const int k) __attribute__((always_inline)) { return c[k <= 9 ? k : 18 - k]; };
+
+    constexpr int SX = SRC_MODE == 2 ? 2 : 1;
+    int col_off[2];
+    {
+        const int xa = x0 - 12 + lane, xb = xa + 64;
+        const bool oka = xa >= 0 && xa < w, okb = lane < FZ_STAGE - 64 && xb >= 0 && xb < w;
+        col_off[0] = oka ? SX * xa * ES : (int)FZ_DROP;
+        col_off[1] = okb ? SX * xb * ES : (int)FZ_DROP;
+    }
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float *)&lds[0][0];
+    int yi_next = y0 - RADIUS;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    auto fetch = [&](const int slot) __attribute__((always_inline)) {
+        const int yi = yi_next++;
+        const unsigned row = (yi >= 0 && yi < h) ? (unsigned)(SX * yi) * (unsigned)src_pitch * (unsigned)ES : FZ_DROP;
+        const unsigned dst = lds_base + (unsigned)slot * 512u;
+        if (SRC_MODE == 1) {
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_ubyte %1, %2, %3 offen lds" ::"s"(dst), "v"(col_off[0]), "s"(src_rs), "s"(row) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_ubyte %1, %2, %3 offen lds" ::"s"(dst + 256u), "v"(col_off[1]), "s"(src_rs), "s"(row) : "memory", "m0");
+        } else {
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(dst), "v"(col_off[0]), "s"(src_rs), "s"(row) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(dst + 256u), "v"(col_off[1]), "s"(src_rs), "s"(row) : "memory", "m0");
+        }
+    };
+#pragma clang diagnostic pop
+    // Row r + 1 must have landed when step r reads its window.  Vector-memory operations issued
+    // after that row's fetch (which step r + 1 - FZP_PF issued): that step's store, FZP_PF - 2 whole
+    // steps of two fetches and a store, and this step's two fetches.
+    constexpr int FZP_WAIT = 1 + 3 * (FZP_PF - 2) + 2;
+    // the 19-pixel window of the row in LDS buffer `slot` (8-bit sources: integers to floats first,
+    // in place; a wave's LDS operations stay in order)
+    auto window = [&](const int slot, float (&win)[TAPS]) __attribute__((always_inline)) {
+        if (SRC_MODE == 1) {
+            const unsigned a0 = __float_as_uint(lds[slot][lane]), a1 = __float_as_uint(lds[slot][lane + 64]);
+            lds[slot][lane] = (float)a0;
+            lds[slot][lane + 64] = (float)a1;
+            asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) win[k] = lds[slot][lane + 3 + k];
+    };
+
+    float acc[COL_RING];
+#pragma unroll
+    for (int k = 0; k < COL_RING; ++k) acc[k] = 0.f;
+    float win_a[TAPS], win_b[TAPS]; // the windows of even and odd rows of a chunk
+
+    auto chunk = [&](const int rb) __attribute__((always_inline)) {
+        static_for<COL_RING>([&](auto rr_c) __attribute__((always_inline)) {
+            constexpr int rr = decltype(rr_c)::value;
+            const int r = rb + rr;
+            __builtin_amdgcn_sched_barrier(0);
+            if (r >= nin) return; // wave-uniform: the strip ended inside this chunk
+            fetch((rr + FZP_PF) % FZP_SLOTS); // row r + FZP_PF goes to the buffer row r - 1 was read from
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FZP_WAIT) : "memory"); // row r + 1 has landed
+            float(&win)[TAPS] = (rr & 1) ? win_b : win_a;
+            float(&nxt)[TAPS] = (rr & 1) ? win_a : win_b;
+            window((rr + 1) % FZP_SLOTS, nxt); // in flight while this row's chains run
+            float vs = 0.f;
+#pragma unroll
+            for (int k = 0; k < TAPS; ++k) vs = __builtin_fmaf(tapk(k), win[k], vs);
+#pragma unroll
+            for (int k = 0; k < TAPS; ++k) {
+                const int slot = (rr - k + COL_RING) % COL_RING;
+                acc[slot] = __builtin_fmaf(tapk(k), vs, k == 0 ? 0.f : acc[slot]);
+            }
+            const bool valid = r >= 2 * RADIUS; // (r < nin holds here)
+            const int vo = out_lane | (valid ? 0 : (int)FZ_DROP);
+            constexpr int e = (rr - 2 * RADIUS + COL_RING) % COL_RING;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[e]), bl_rs, vo, (int)out_row, PYRP_STORE_POLICY);
+            out_row += valid ? (unsigned)p * 4u : 0u;
+        });
+    };
+    // prologue: the first FZP_PF rows, waited for in full; the first row's window
+#pragma unroll
+    for (int q = 0; q < FZP_PF; ++q) fetch(q);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    window(0, win_a);
+    for (int rb = 0; rb < nin; rb += COL_RING) chunk(rb);
+    // rows fetched beyond the strip's last are still on their way into this block's LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------
 // The same pass with TWO columns per lane: a wave owns 128 columns, lane l the columns
 // x0 + 2l and x0 + 2l + 1.  Every packed FMA then works on the two columns of one plane
 // (the tap is one scalar for both halves), each plane row leaves the wave as one 512-byte
@@ -2581,6 +2730,10 @@ int g_strip_override = 0; // > 0: rows per strip of the pyramid pass, for experi
 // g_pyr2_min_w wide (reference profile)
 int g_pyr_cols = 1;
 int g_pyr2_min_w = 512;
+// cost of a row step of pyramid_plane_kernel in 0.01 us: a wave alone on its SIMD, and what each
+// further wave per SIMD adds
+constexpr long PLANE_STEP_ALONE = 19, PLANE_STEP_SHARED = 10;
+constexpr long PLANE_SPLIT_MAX_PX = 1000000; // pixels of a launch (all its images) up to which the planes are dealt over waves
 
 // Rows per strip of the fused pyramid pass.  A wave walks its strip row by row and needs 18
 // rows of apron, so a strip of r rows costs r + 18 row steps.
@@ -2652,10 +2805,32 @@ int pyramid_strip_rows_search(int w, int h, int nimg, int n_scales, int cols_per
     return best_rows;
 }
 
+// Rows per strip of pyramid_plane_kernel (single-round launches only): steps x the cost of a step
+// with that many waves per SIMD, in units of 0.01 us.
+int g_pyr_split = 1; // 0: never use pyramid_plane_kernel
+int plane_strip_rows(int w, int h, int nimg, int np)
+{
+    if (g_strip_override > 0) return g_strip_override < h ? g_strip_override : h;
+    const long simds = 256L * 4;
+    const long gx = idivup(w, 64);
+    long best_t = -1;
+    int best_rows = h;
+    for (int n = 1; n <= h; ++n) {
+        const int rows = idivup(h, n);
+        if (n > 1 && rows == idivup(h, n - 1)) continue;
+        const long waves = gx * idivup(h, rows) * nimg * np;
+        if (waves > 8 * simds) break;
+        const long t = (rows + 2 * RADIUS) * (PLANE_STEP_ALONE + PLANE_STEP_SHARED * waves / simds);
+        if (best_t < 0 || t < best_t) best_t = t, best_rows = rows;
+    }
+    return best_rows;
+}
+
 } // namespace
 
 extern "C" {
 
+void hl_set_pyramid_split(int on) { g_pyr_split = on != 0; }
 void hl_set_pyramid_strip_rows(int rows) { g_strip_override = rows; }
 void hl_set_pyramid_columns(int cols, int min_width)
 {
@@ -2890,6 +3065,34 @@ int hl_pyramid(const void *src, int src_w, int src_h, int src_pitch, long src_st
         }
 #undef PYR2_LAUNCH
         return launch_status();
+    }
+    if (!queue && g_pyr_split) {
+        // A launch the chip holds in a single round and that feeds no candidate queue (one image at a
+        // time, the stage entry): the planes dealt over waves.
+        const int rows1 = pyramid_strip_rows(w, h, nimg, n_scales, 1);
+        const long slots = 256L * 4 * (n_scales == 2 ? PYR_WAVES_S2 : PYR_WAVES_S3);
+        // (a launch of more pixels is bound by the chip's FMA rate, not by its longest wave, and
+        // staging every source row S+3 times costs more than the shorter row steps give back: one
+        // 1080p image 30 us against 26, its second octave 16 against 18, its fifth 6 against 10)
+        if ((long)idivup(w, 64) * idivup(h, rows1) * nimg <= slots && (long)w * h * nimg <= PLANE_SPLIT_MAX_PX) {
+            const int np = n_scales + 3;
+            const int rows = plane_strip_rows(w, h, nimg, np);
+            const dim3 tiles(idivup(w, 64), idivup(h, rows), nimg), block(64);
+            const dim3 grid(tiles.x * tiles.y * tiles.z * np);
+            hipStream_t s = (hipStream_t)stream;
+            ScopedTimer t(4, s);
+#define PYRP_LAUNCH(MD)                                                                              \
+    hipLaunchKernelGGL((pyramid_plane_kernel<MD>), grid, block, 0, s, (const float *)src, src_w,     \
+                       src_h, src_pitch, src_stride, blur, blur_stride, w, p, h, rows, np, *taps,    \
+                       (int)tiles.x, (int)tiles.y, (int)tiles.z)
+            switch (src_mode) {
+            case 0: PYRP_LAUNCH(0); break;
+            case 1: PYRP_LAUNCH(1); break;
+            default: PYRP_LAUNCH(2); break;
+            }
+#undef PYRP_LAUNCH
+            return launch_status();
+        }
     }
     const int rows = pyramid_strip_rows(w, h, nimg, n_scales, 1);
     const dim3 tiles(idivup(w, 64), idivup(h, rows), nimg), block(64);

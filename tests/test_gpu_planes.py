@@ -103,6 +103,57 @@ def test_two_columns_per_lane_planes_and_points_match_the_oracle(sift, oracle_mo
         sift.set_params()
 
 
+@pytest.mark.parametrize(
+    "w,h,S,O,u8,pitch_extra",
+    [(1920, 1080, 2, 5, False, 0),   # one 1080p image: every octave a single round of waves
+     (640, 480, 3, 4, False, 0),     # three scales: six planes, six waves per tile
+     (801, 603, 2, 5, True, 0),      # 8-bit source, odd sizes down to 51x38
+     (333, 129, 3, 3, False, 5),     # ragged, pitched with garbage in the pad columns
+     (97, 70, 2, 2, True, 0),
+     (1000, 37, 2, 2, False, 0)],    # wider than tall: one strip of 37 rows
+)
+def test_plane_per_wave_kernel_planes_and_points_match_the_oracle(sift, oracle_mod, w, h, S, O, u8, pitch_extra):
+    """pyramid_plane_kernel (one blur plane per wave; the pyramid pass of launch sets small enough for
+    the dense route): the planes of every octave bit for bit against the oracle's row pass, column
+    pass and down-sampling, and the keypoints; then the same call with the kernel switched off."""
+    kw = dict(n_scales=S, n_octaves=O, max_points=30000)
+    sift.set_params(**kw)
+    pr = oracle_mod.params(**kw)
+    L = sift.lib()
+    try:
+        L.sift_set_dense_route_pixels(4000000)
+        img = sift.synth_image(w, h, seed=9100 + w, dense=True)
+        ref, _, total = oracle_mod.extract(pr, img, w)
+        assert 0 < total == len(ref)
+        want = oracle_mod.sort_points(ref).tobytes()
+        if u8:  # the 8-bit entry is a batch entry: a batch of one
+            d = torch.from_numpy(img.astype(np.uint8)[None]).cuda()
+            for split in (1, 0):
+                L.sift_set_pyramid_split(split)
+                d_pts, counts = sift.extract_batch(d, w)
+                slot, k = sift.debug_batch_slot(1, 0)
+                _assert_octaves_equal(sift, oracle_mod, pr, img, w, slot, k, O, f"split {split} u8 {w}x{h}")
+                got = sift.points_to_numpy(d_pts, int(counts[0]))
+                assert oracle_mod.sort_points(got).tobytes() == want, f"split {split}"
+        else:
+            pitch = w + pitch_extra
+            host = oracle_mod.pitched(img[:, :w], pitch, fill=-1e30) if pitch_extra else img
+            d = torch.from_numpy(host).cuda()
+            for split in (1, 0):
+                L.sift_set_pyramid_split(split)
+                pts = sift.new_point_buffer()
+                sift.initDeviceVariables()
+                sift.extractSift(pts, d, w, pitch, h, None, 1, 0)
+                n = sift.getPointCount(1)
+                _assert_octaves_equal(sift, oracle_mod, pr, host, w, 1, 0, O, f"split {split} {w}x{h}")
+                assert sum(sift.group_counts(1)[1]) == 0  # no queue was fed: the dense route
+                assert oracle_mod.sort_points(sift.points_to_numpy(pts, n)).tobytes() == want, f"split {split}"
+    finally:
+        L.sift_set_pyramid_split(1)
+        L.sift_set_dense_route_pixels(0)
+        sift.set_params()
+
+
 def test_fused_kernel_planes_through_extractSift_with_a_pitch(sift, oracle_mod):
     """The reference entry point on a pitched image whose pad columns hold garbage."""
     kw = dict(n_scales=2, n_octaves=4, max_points=20000)

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/lat1
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
-for r in 0 2 4 8 16 32; do
+for r in 0 1 2 4 8 16 32 64; do
   timeout -k 10 120 rocprofv3 --kernel-trace --output-format csv -d $O/tr$r -- python3 tools/latency_probe.py --iters 30 --strip-rows $r > $O/prof$r.log 2>&1
   python3 tools/timeline.py $O/tr$r 11 > $O/timeline$r.txt 2>&1
   rm -rf $O/tr$r
