@@ -223,6 +223,10 @@ void sift_set_pyramid_columns(int cols, int min_width);
  * waves, for calls whose time is the sum of their launches' longest waves.  on = 0 keeps the
  * one-wave-per-tile kernel for them too (default 1).  Results do not depend on it. */
 void sift_set_pyramid_split(int on);
+/* Diagnostics: the strip height (rows) a pyramid launch of `images` images of width x height would
+ * be cut into, whatever sift_set_strip_rows says.  kernel 0: one wave per tile (pyramid_kernel),
+ * 1: one plane per wave, 2: two columns per lane.  Needs no GPU.  -1 for bad arguments. */
+int sift_debug_strip_rows(int width, int height, int images, int n_scales, int kernel);
 /* launch sets in flight at once, each on a private stream and arena: 1 or 2
  * (default 2: the short kernels of the small octaves of one set overlap the
  * long kernels of the other) */

@@ -78,6 +78,7 @@ SYMBOLS = {
     "sift_set_batch_chunk": (None, [C.c_int]),
     "sift_set_pyramid_columns": (None, [C.c_int, C.c_int]),
     "sift_set_pyramid_split": (None, [C.c_int]),
+    "sift_debug_strip_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "sift_set_batch_lanes": (None, [C.c_int]),
     "sift_set_queue_cap": (None, [C.c_int]),
     "sift_set_dense_route_pixels": (None, [C.c_long]),

@@ -93,6 +93,9 @@ void hl_set_pyramid_strip_rows(int rows);
 /* 0: single-round launches without a candidate queue keep pyramid_kernel (default 1: the planes
  * are dealt over waves, pyramid_plane_kernel) */
 void hl_set_pyramid_split(int on);
+/* rows per strip the launchers would choose (kind 0: pyramid_kernel, 1: pyramid_plane_kernel,
+ * 2: pyramid2_kernel), ignoring any override; -1 for bad arguments */
+int hl_debug_strip_rows(int w, int h, int nimg, int n_scales, int kind);
 /* columns per lane of the pyramid pass: 1, or 2 for octaves at least min_width wide (0 = keep) */
 void hl_set_pyramid_columns(int cols, int min_width);
 

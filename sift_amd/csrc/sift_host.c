@@ -932,6 +932,10 @@ int sift_debug_batch_slot(int n, int i, int *slot, int *image)
 void sift_set_strip_rows(int rows) { hl_set_pyramid_strip_rows(rows > 0 ? rows : 0); }
 void sift_set_pyramid_columns(int cols, int min_width) { hl_set_pyramid_columns(cols, min_width); }
 void sift_set_pyramid_split(int on) { hl_set_pyramid_split(on); }
+int sift_debug_strip_rows(int width, int height, int images, int n_scales, int kernel)
+{
+    return hl_debug_strip_rows(width, height, images, n_scales, kernel);
+}
 
 /* h_counts != NULL: the counts go to the host and the call blocks until they are there.
  * Otherwise they go to d_counts (device, n words) and the call returns after enqueueing. */

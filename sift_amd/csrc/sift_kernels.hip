@@ -2836,6 +2836,14 @@ int plane_strip_rows(int w, int h, int nimg, int np)
 extern "C" {
 
 void hl_set_pyramid_split(int on) { g_pyr_split = on != 0; }
+int hl_debug_strip_rows(int w, int h, int nimg, int n_scales, int kind)
+{
+    if (w < 1 || h < 1 || nimg < 1 || (n_scales != 2 && n_scales != 3)) return -1;
+    if (kind == 0) return pyramid_strip_rows_search(w, h, nimg, n_scales, 1);
+    if (kind == 1) return plane_strip_rows(w, h, nimg, n_scales + 3);
+    if (kind == 2) return pyramid_strip_rows_search(w, h, nimg, n_scales, 2);
+    return -1;
+}
 void hl_set_pyramid_strip_rows(int rows) { g_strip_override = rows; }
 void hl_set_pyramid_columns(int cols, int min_width)
 {

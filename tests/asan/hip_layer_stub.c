@@ -95,6 +95,7 @@ const char *hl_error_string(int code)
 void hl_set_pyramid_strip_rows(int rows) { (void)rows; }
 void hl_set_pyramid_columns(int cols, int min_width) { (void)cols, (void)min_width; }
 void hl_set_pyramid_split(int on) { (void)on; }
+int hl_debug_strip_rows(int w, int h, int nimg, int n_scales, int kind) { (void)w, (void)nimg, (void)n_scales, (void)kind; return h; }
 static unsigned char g_scratch[2][32u << 20];
 int hl_scratch(void **ptr, size_t *bytes)
 {

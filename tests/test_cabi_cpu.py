@@ -290,3 +290,27 @@ int main() { return 0; }
            "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_strip_heights_of_the_pyramid_launches(sift):
+    """The launch shapes the measurements were made with: a batch that fills the chip many times over
+    is cut into few tall strips (18 apron rows per strip are wasted work), a launch the chip holds in
+    one round into strips priced by the waves that share a SIMD.  Host arithmetic only."""
+    rows = sift.lib().sift_debug_strip_rows
+    # BASELINE configs[2]: 256 images of 1920x1080, 2 scales, octave after octave
+    assert [rows(w, h, 256, 2, 0) for (w, h) in ((1920, 1080), (960, 540), (480, 270), (240, 135))] == [540, 135, 90, 45]
+    # one 1080p image: the first octave with one wave per tile, the later ones with one plane per wave
+    assert rows(1920, 1080, 1, 2, 0) == 16
+    assert 1 <= rows(120, 68, 1, 2, 0) <= 2
+    for (w, h) in ((960, 540), (480, 270), (240, 135), (120, 68)):
+        r = rows(w, h, 1, 2, 1)
+        waves = -(-w // 64) * -(-h // r) * 5
+        assert 1 <= r <= h and waves <= 8 * 1024, (w, h, r)
+    assert rows(960, 540, 1, 2, 1) > rows(120, 68, 1, 2, 1)
+    # any geometry gives strips inside the image
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        w, h, n, s = int(rng.integers(1, 5000)), int(rng.integers(1, 3000)), int(rng.integers(1, 300)), int(rng.integers(2, 4))
+        for kind in (0, 1, 2):
+            assert 1 <= rows(w, h, n, s, kind) <= h
+    assert rows(0, 10, 1, 2, 0) == -1 and rows(10, 10, 1, 4, 0) == -1 and rows(10, 10, 1, 2, 7) == -1
