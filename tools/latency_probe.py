@@ -2,7 +2,7 @@
 """Runs the reference's call sequence (initDeviceVariables + extractSift + getPointCount) on one
 resident image a number of times and prints the median wall time; meant to be run under
 `rocprofv3 --kernel-trace` as well, for tools/timeline.py.
-usage: latency_probe.py [--iters N] [--strip-rows R] [--size WxH] [--queue-cap C]"""
+usage: latency_probe.py [--iters N] [--strip-rows R] [--size WxH] [--queue-cap C] [--photo]"""
 import argparse
 import os
 import sys
@@ -20,6 +20,7 @@ ap.add_argument("--iters", type=int, default=200)
 ap.add_argument("--strip-rows", type=int, default=0)
 ap.add_argument("--size", default="1920x1080")
 ap.add_argument("--queue-cap", type=int, default=-1)
+ap.add_argument("--photo", action="store_true", help="photograph density: the committed crop of Sift/img/img1.ppm tiled to the size")
 a = ap.parse_args()
 w, h = (int(v) for v in a.size.split("x"))
 sift.set_params(n_octaves=5, n_scales=2, max_points=2500)
@@ -29,6 +30,10 @@ if a.strip_rows:
 if a.queue_cap >= 0:
     sift.lib().sift_set_queue_cap(a.queue_cap)
 img = sift.synth_image(w, h, seed=1000)
+if a.photo:
+    g = np.load(os.path.join(ROOT, "tests", "golden", "real_img1_crop.npz"))["gray"].astype(np.float32)
+    row = np.concatenate([g, g[:, ::-1]] * (w // 640 + 1), axis=1)
+    img = np.ascontiguousarray(np.concatenate([row, row[::-1]] * (h // 512 + 1), axis=0)[:h, :w])
 d = torch.from_numpy(img).cuda()
 pts = sift.new_point_buffer()
 
