@@ -131,6 +131,13 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `make -C sift_amd/csrc` "
                 "(or __graft_entry__.build()); there is no CPU fallback"
             )
+        # Device memory and streams come from PyTorch, which ships a HIP runtime of its own.  The
+        # library must bind to that copy: loaded before torch it binds to /opt/rocm's, the process
+        # then holds two runtimes, and the library's sees no usable device.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)
