@@ -63,7 +63,7 @@ def test_pyramid_stages_on_random_shapes(sift, oracle_mod):
 DENSE_ROUTE_DEFAULT = 2200000  # sift_set_dense_route_pixels' default (include/sift_amd.h)
 
 
-def _extract_gpu(sift, img_host, w):
+def _extract_gpu(sift, img_host, w, both=False):
     """One image through the reference's call sequence, twice: by the queue route (pre-filter in the
     pyramid pass, candidate verification) and by the route the library takes by default for a job
     this small (dense detector alone).  The two must give the same points."""
@@ -86,7 +86,28 @@ def _extract_gpu(sift, img_host, w):
     if sift.get_params().max_points > max(len(o) for o in outs):  # (over the cap the survivors are any subset)
         assert oracle.sort_points(outs[0]).tobytes() == oracle.sort_points(outs[1]).tobytes(), \
             "dense route and queue route disagree"
-    return outs[1]
+    return outs if both else outs[1]
+
+
+def _assert_capped_like_the_reference(oracle_mod, got, every, cap):
+    """Over the cap the reference keeps its groups in order: (octave, scale) groups are filled one
+    after the other and everything after the cap is reached is skipped (cudaSiftH.cu:12-13, 82), so
+    the output is every point of the groups before the one that overflows plus cap - (their number)
+    points of that group, any of them (the append order inside a group is an atomic's).  `every` is
+    the oracle's list without a cap; a point's group is known from its scale value, which is unique
+    per (octave, scale) (cudaSiftH.cu:94-95)."""
+    got = got.view(oracle_mod.POINT_DTYPE)
+    assert len(got) == min(cap, len(every))
+    scales = sorted(set(every["scale"].tolist()))  # ascending scale = group order
+    have = {r.tobytes() for r in every}
+    assert all(r.tobytes() in have for r in got), "a point that is not in the uncapped list"
+    assert len({r.tobytes() for r in got}) == len(got), "a point twice"
+    room = cap
+    for sc in scales:
+        n_ref = int((every["scale"] == sc).sum())
+        n_got = int((got["scale"] == sc).sum())
+        assert n_got == min(n_ref, room), f"group of scale {sc}: {n_got} points, expected {min(n_ref, room)}"
+        room -= n_got
 
 
 def _assert_points_equal(oracle_mod, got, ref):
@@ -152,9 +173,11 @@ def test_reference_sample_images_at_full_size(sift, oracle_mod, key):
         got = sift.points_to_numpy(pts, int(counts[0])).view(oracle_mod.POINT_DTYPE)
         assert oracle_mod.sort_points(got).tobytes() == want
     _params(sift, oracle_mod, n_scales=2, n_octaves=4, max_points=2500)
-    got = _extract_gpu(sift, g, w).view(oracle_mod.POINT_DTYPE)
-    have = {r.tobytes() for r in ref}
-    assert len(got) == min(2500, total) and all(r.tobytes() in have for r in got)
+    for got in _extract_gpu(sift, g, w, both=True):  # the dense route and the queue route
+        _assert_capped_like_the_reference(oracle_mod, got, ref, 2500)
+    for stack in (g[None], g8[None]):
+        pts, counts = sift.extract_batch(torch.from_numpy(np.ascontiguousarray(stack)).cuda(), w)
+        _assert_capped_like_the_reference(oracle_mod, sift.points_to_numpy(pts, int(counts[0])), ref, 2500)
     sift.set_params()
 
 
@@ -253,15 +276,13 @@ def test_cap_reached_while_the_dense_detector_runs(sift, oracle_mod, queue_cap, 
     img = sift.synth_image(w, h, seed=196340271, dense=True)
     every, _, total = oracle_mod.extract(oracle_mod.params(max_points=400000, **kw), img, w)
     assert total == len(every) > 300000
-    have = {r.tobytes() for r in every}
     sift.set_params(max_points=cap, **kw)
     sift.lib().sift_set_queue_cap(queue_cap)
     try:
         for _ in range(3):  # the interleaving differs from run to run
-            got = _extract_gpu(sift, img, w).view(oracle_mod.POINT_DTYPE)
-            assert len(got) == cap
-            assert all(r.tobytes() in have for r in got)
-            assert len({r.tobytes() for r in got}) == cap
+            for got in _extract_gpu(sift, img, w, both=True):  # (one image: with and without the dense route)
+                assert len(got) == cap
+                _assert_capped_like_the_reference(oracle_mod, got, every, cap)
     finally:
         sift.lib().sift_set_queue_cap(65536)
         sift.set_params()
