@@ -927,6 +927,17 @@ def test_list_pipeline_on_several_workers_matches_the_pairwise_pipeline(sift, or
         assert names == sorted(os.listdir(out)) and len(names) == len(paths)
         for f in names:
             assert filecmp.cmp(base / f, out / f, shallow=False), f"{f} differs with {workers} workers"
+    # the same with the library's default rule for small launch sets (batches of these small images
+    # fall under the pixel limit: dense detector alone, one blur plane per wave)
+    sift.lib().sift_set_dense_route_pixels(DENSE_ROUTE_DEFAULT)
+    try:
+        out = tmp_path / "multi_dense_route"
+        out.mkdir()
+        assert sift.extract_list_multi(paths, str(out), 2).tolist() == ref_counts
+        for f in sorted(os.listdir(base)):
+            assert filecmp.cmp(base / f, out / f, shallow=False), f"{f} differs on the dense route"
+    finally:
+        sift.lib().sift_set_dense_route_pixels(0)
     # without a destination only the counts come back
     assert sift.extract_list_multi(paths[:5], None, 2).tolist() == ref_counts[:5]
     with pytest.raises(sift.SiftError, match="missing.pgm"):  # the worker thread's message reaches the caller
