@@ -40,12 +40,20 @@ def _same(oracle_mod, a, b):
     assert a.tobytes() == b.tobytes()
 
 
-def test_no_alloc_entry_matches_the_batch_entry_twice_in_a_row(sift, oracle_mod):
+@pytest.mark.parametrize("dense_route_pixels", [0, 2200000])
+def test_no_alloc_entry_matches_the_batch_entry_twice_in_a_row(sift, oracle_mod, dense_route_pixels):
+    """Both ways a one-image job can be detected: through the candidate queues (limit 0) and, the
+    library's default for a job this small, by the dense detector alone behind the plane-per-wave
+    pyramid kernel; the batch entry it is compared with always takes the queues."""
     sift.set_params(n_scales=2, n_octaves=4, max_points=2500)
     big = sift.synth_image(800, 640, seed=501, pitch=832)          # the reference's own image size, pitched
     small = sift.synth_image(333, 200, seed=502, dense=True)       # smaller, ragged
-    got_big = _noalloc(sift, big, 800)
-    got_small = _noalloc(sift, small, 333)                          # second call: stale scratch around it
+    try:
+        sift.lib().sift_set_dense_route_pixels(dense_route_pixels)
+        got_big = _noalloc(sift, big, 800)
+        got_small = _noalloc(sift, small, 333)                      # second call: stale scratch around it
+    finally:
+        sift.lib().sift_set_dense_route_pixels(0)
     _same(oracle_mod, got_big, _batch_entry(sift, np.ascontiguousarray(big), 800))
     _same(oracle_mod, got_small, _batch_entry(sift, small, 333))
     # and the oracle agrees with both
