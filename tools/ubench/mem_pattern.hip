@@ -249,6 +249,72 @@ template <int PF, int LDSB> static void run_rows4(int rows)
     fflush(stdout);
 }
 
+// The kernel's shape (64 columns per wave, one wave per workgroup, strips of rows, planar) with the mix
+// taken apart: NPLX planes written per row (0..5), with (READ = 1) or without the source row read.
+// SPLIT = 1: twice the waves, every second one only reads its tile's source rows and the others only
+// write the planes: the same bytes in the same launch, but no wave waits for a load behind its stores.
+template <int NPLX, int READ, int LDSB, int SPLIT, int PF>
+__global__ __launch_bounds__(64) void strips_mix(float *__restrict__ out, const float *__restrict__ in, int w, int p, int h,
+                                                 int rows, long out_stride, float a, float b)
+{
+    __shared__ float occ[LDSB / 4 + 1];
+    if (a == 12345.f) occ[threadIdx.x] = b;
+    if (a == 54321.f) out[0] = occ[threadIdx.x + 1];
+    const unsigned gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * gridDim.z;
+    const unsigned orig = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned q = nwg / 8, r = nwg % 8, xcd = orig % 8;
+    unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+    // SPLIT = 2: every image reads the source rows of image 0, so the reads hit in the caches and HBM sees writes only
+    const bool reads = SPLIT == 1 ? (t & 1u) == 0 : READ != 0, writes = SPLIT == 1 ? (t & 1u) != 0 : NPLX > 0;
+    if (SPLIT == 1) t >>= 1;
+    const int tx = (int)(t % gx), ty = (int)((t / gx) % gy), tz = (int)(t / (gx * gy));
+    const int x = tx * 64 + threadIdx.x;
+    if (x >= w) return;
+    const int y0 = ty * rows, y1 = min(y0 + rows, h);
+    const long plane = (long)p * h;
+    const float *s = in + (SPLIT == 2 ? 0 : tz) * plane + x;
+    float *o = out + tz * out_stride + x;
+    float g[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) g[k] = reads ? s[(long)min(y0 + k, h - 1) * p] : a;
+    float sink = 0.f;
+    for (int y = y0; y < y1; y += PF) {
+        float cur[PF];
+        if (SPLIT == 3) { // the PF loads of the next chunk go out together, then PF rows of stores
+#pragma unroll
+            for (int k = 0; k < PF; ++k) cur[k] = g[k];
+#pragma unroll
+            for (int k = 0; k < PF; ++k) g[k] = s[(long)min(y + k + PF, h - 1) * p];
+        }
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const float v = SPLIT == 3 ? cur[k] : g[k];
+            if (SPLIT != 3 && reads) g[k] = s[(long)min(y + k + PF, h - 1) * p];
+            if (y + k < y1) {
+                if (!writes) sink += v;
+                else {
+#pragma unroll
+                    for (int i = 0; i < NPLX; ++i) o[i * plane + (long)(y + k) * p] = v + (float)i;
+                }
+            }
+        }
+    }
+    if (!writes && sink == 123.456f) out[0] = sink;
+}
+template <int NPLX, int READ, int LDSB, int SPLIT = 0, int PF = 4> static void run_mix(int rows)
+{
+    const long plane = (long)P * H;
+    dim3 grid(W / 64, (H + rows - 1) / rows, NIMG * (SPLIT == 1 ? 2 : 1));
+    const float ms = best_ms([&] {
+        hipLaunchKernelGGL((strips_mix<NPLX, READ, LDSB, SPLIT, PF>), grid, dim3(64), 0, 0, g_out, g_in, W, P, H, rows, plane * NPL, 0.999f,
+                           0.001f);
+    });
+    const double bytes = (double)plane * NIMG * 4 * (NPLX + (READ ? 1 : 0));
+    printf("kernel's shape, %d plane(s) written, %2d rows ahead, source row %s, lds=%5d: %7.3f ms  %5.2f TB/s\n", NPLX, PF,
+           SPLIT == 3 ? "read in bursts" : SPLIT == 1 ? "read by other waves" : (SPLIT == 2 ? "read from the caches" : (READ ? "read    " : "not read")), LDSB, ms, bytes / ms / 1e9);
+    fflush(stdout);
+}
+
 int main(int argc, char **argv)
 {
     const int set = argc > 1 ? atoi(argv[1]) : 0;
@@ -302,6 +368,41 @@ int main(int argc, char **argv)
         run<1, 1, 0, 38, 4, 13000, 1, 0, 1>(540, 3072);
         run<2, 1, 0, 38, 4, 20000>(540);
         run<2, 1, 0, 38, 4, 20000, 1, 0, 1>(540, 2048);
+    }
+    if (set == 3) { // the mix taken apart, at the kernel's occupancy (3 waves per SIMD) and unthrottled
+        run_mix<0, 1, 13000>(540);
+        run_mix<1, 1, 13000>(540);
+        run_mix<2, 1, 13000>(540);
+        run_mix<3, 1, 13000>(540);
+        run_mix<5, 1, 13000>(540);
+        run_mix<1, 0, 13000>(540);
+        run_mix<2, 0, 13000>(540);
+        run_mix<3, 0, 13000>(540);
+        run_mix<5, 0, 13000>(540);
+        run_mix<0, 1, 0>(540);
+        run_mix<1, 1, 0>(540);
+        run_mix<5, 1, 0>(540);
+        run_mix<1, 0, 0>(540);
+        run_mix<5, 0, 0>(540);
+        run_mix<5, 1, 13000, 1>(540);
+        run_mix<5, 1, 6500, 1>(540);
+        run_mix<5, 1, 0, 1>(540);
+        run_mix<1, 1, 13000, 1>(540);
+        run_mix<5, 1, 13000, 2>(540);
+        run_mix<5, 1, 0, 2>(540);
+        run_mix<1, 1, 13000, 2>(540);
+        run_mix<5, 1, 13000, 0, 2>(540);
+        run_mix<5, 1, 13000, 0, 6>(540);
+        run_mix<5, 1, 13000, 0, 8>(540);
+        run_mix<5, 1, 13000, 0, 10>(540);
+        run_mix<5, 1, 13000, 0, 20>(540);
+        run_mix<5, 1, 13000, 3, 4>(540);
+        run_mix<5, 1, 13000, 3, 8>(540);
+        run_mix<5, 1, 13000, 3, 16>(540);
+        run_mix<5, 1, 0, 3, 16>(540);
+        run_mix<5, 1, 13000, 2, 8>(540);
+        run_mix<5, 1, 13000, 2, 10>(540);
+        run_mix<5, 1, 13000, 2, 20>(540);
     }
     return 0;
 }
