@@ -372,8 +372,13 @@ __global__ __launch_bounds__(64, (S == 2 ? PYR_WAVES_S2 : PYR_WAVES_S3)) void py
     // buffer descriptors (wave-uniform): 32-bit per-lane offsets in one VGPR and
     // per-row / per-plane offsets in scalar registers replace 64-bit per-lane
     // address arithmetic
+#ifdef PYR_EXP_SRC0 // experiment (results are wrong): every image reads the first image's source, so the reads hit in the caches
+    const int zs = 0;
+#else
+    const int zs = z;
+#endif
     const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(src) + z * src_stride * ES), 0,
+        const_cast<char *>(reinterpret_cast<const char *>(src) + zs * src_stride * ES), 0,
         (int)(unsigned)min((long)src_pitch * src_h * ES, 0xffffffffL), 0x00020000);
     const __amdgpu_buffer_rsrc_t bl_rs = __builtin_amdgcn_make_buffer_rsrc(
         blur + z * blur_stride, 0, (int)(unsigned)min(plane * NP * 4, (long)FZ_DROP), 0x00020000);
